@@ -1,0 +1,34 @@
+"""Helpers shared by the CPU (oracle) and GPU (HIP) replays of the committed golden fixtures."""
+import glob
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def fixture_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    d = {k: z[k] for k in z.files}
+    d["meta"] = json.loads(str(d["meta"]))
+    return d
+
+
+def config_overrides(meta):
+    """Reference constructor kwargs (uav_env.py:266-287) -> config field names shared by the oracle's
+    OrcConfig and the product's UavEnvConfig."""
+    kw = dict(meta["kwargs"])
+    over = dict(grid_size=tuple(meta["grid"]), num_sensors=meta["n"])
+    if "sensor_duty_cycle" in kw:
+        over["duty_cycle"] = kw.pop("sensor_duty_cycle")
+    if "uav_start_position" in kw:
+        over["start_x"], over["start_y"] = kw.pop("uav_start_position")
+    over.update(kw)
+    if meta["sigma"] is not None:
+        over["shadowing_std_db"] = meta["sigma"]
+    return over
