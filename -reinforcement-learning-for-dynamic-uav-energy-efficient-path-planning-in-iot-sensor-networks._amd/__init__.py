@@ -1,0 +1,15 @@
+"""MI355X-native batched UAV-IoT data-collection environment (one hot path of the reference:
+UAVEnvironment.reset()/step(), /root/reference/src/environment/uav_env.py:400-488).
+
+    from uavenv_amd import BatchedUAVEnv, UAVEnvironment, UAVVecEnv
+
+The compute lives in csrc/ (hand-written HIP for gfx950) behind the C ABI of include/uavenv.h;
+this package is the Python host side that mirrors the reference's gymnasium / SB3 interfaces.
+"""
+from . import _native
+from ._native import (FLAG_AUTO_RESET, FLAG_FAR_START, FLAG_JAIN_BONUS, FLAG_PROX_SHAPING, FLAG_RANDOM_LAYOUT,
+                      UavEnvConfig, UavEnvError, default_config)
+from .batched_env import BatchedUAVEnv, config_from_kwargs
+
+__all__ = ["BatchedUAVEnv", "UavEnvConfig", "UavEnvError", "default_config", "config_from_kwargs",
+           "FLAG_AUTO_RESET", "FLAG_FAR_START", "FLAG_JAIN_BONUS", "FLAG_PROX_SHAPING", "FLAG_RANDOM_LAYOUT"]

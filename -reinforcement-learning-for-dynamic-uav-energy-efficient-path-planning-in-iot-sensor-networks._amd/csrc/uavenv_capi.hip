@@ -1,0 +1,400 @@
+// uavenv_capi.hip -- the extern "C" boundary declared in include/uavenv.h.
+//
+// Owns the HBM state of one shard of environments (SoA sensor arrays + one 128-byte record per
+// environment), derives the kernel constants from UavEnvConfig with the reference's own
+// expressions, validates arguments on the host and launches the kernels of uavenv_kernels.hip on
+// the caller's stream.  Nothing here throws or aborts: every entry point returns a status code.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "uavenv_internal.h"
+
+using namespace uavenv;
+
+struct UavEnv {
+    UavEnvConfig cfg;
+    Consts consts;
+    Ptrs ptrs;
+    int32_t num_envs = 0, padded_envs = 0, G = 64, device = 0;
+    uint32_t env_index_base = 0;
+    void* block = nullptr;          // one hipMalloc holding every state array
+    size_t block_bytes = 0;
+    // host-staging buffers for the *_host convenience entry points
+    int32_t* h_actions_dev = nullptr; float* h_obs_dev = nullptr; double* h_rew_dev = nullptr;
+    uint8_t* h_done_dev = nullptr; float* h_term_dev = nullptr; uint8_t* h_mask_dev = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+};
+
+static thread_local std::string g_create_error;
+
+static int fail(UavEnv* e, int code, const std::string& msg) {
+    if (e) e->err = msg; else g_create_error = msg;
+    return code;
+}
+#define HIP_TRY(e, call)                                                                         \
+    do {                                                                                         \
+        hipError_t _s = (call);                                                                  \
+        if (_s != hipSuccess)                                                                    \
+            return fail((e), UAVENV_E_HIP, std::string(#call) + ": " + hipGetErrorString(_s));   \
+    } while (0)
+
+extern "C" int uavenv_abi_version(void) { return UAVENV_ABI_VERSION; }
+
+extern "C" int uavenv_default_config(UavEnvConfig* c) {
+    if (!c) return UAVENV_E_INVALID;
+    std::memset(c, 0, sizeof(*c));
+    c->struct_size = (uint32_t)sizeof(*c);
+    c->grid_w = 500; c->grid_h = 500;                 // dqn.py EVAL_GRID / BASELINE configs
+    c->num_sensors = 20;                              // uav_env.py:270
+    c->max_steps = 2100;                              // dqn.py:1069
+    c->include_sensor_positions = 0;                  // uav_env.py:286
+    c->pad_sensors = 0;
+    c->flags = 0;
+    c->max_start_tries = 200;                         // dqn.py NAV_CONFIG
+    c->use_ema_adr = 1;                               // iot_sensors.py:54
+    c->num_grid_choices = 0;
+    c->seed = 0;
+    c->data_generation_rate = 22.0 / 10;              // uav_env.py:271
+    c->max_buffer_size = 1000.0;                      // :272
+    c->rssi_threshold = -85.0;                        // :275
+    c->duty_cycle = 10.0;                             // :276
+    c->start_x = 0.0; c->start_y = 0.0;               // :322-323
+    c->max_battery = 274.0;                           // :278
+    c->collection_duration = 1.0;                     // :279
+    c->tx_power_dbm = 14.0;                           // iot_sensors.py:45
+    c->noise_floor_dbm = -105.0;                      // :49
+    c->uav_altitude = 100.0;                          // :50
+    c->sensor_height = 0.5;                           // :170
+    c->wavelength = 0.345;                            // :174
+    c->freq_mhz = 868.0; c->fspl_offset_db = 28.0;    // :179
+    c->adr_lambda = 0.1;                              // :53
+    c->shadowing_std_db = 4.0;                        // :55
+    c->capture_threshold_db = 6.0;                    // uav_env.py:567
+    c->sf_thresholds[0] = -60.0; c->sf_thresholds[1] = -70.0;   // iot_sensors.py:32-37
+    c->sf_thresholds[2] = -78.0; c->sf_thresholds[3] = -85.0;
+    c->fill_lo = 0.20; c->fill_hi = 0.60;             // uav_env.py:410
+    c->power_move = 500.0; c->power_hover = 700.0;    // uav.py:93-94
+    c->alive_fraction = 0.02;                         // uav.py:224
+    c->reward_per_byte = 100.0; c->reward_new_sensor = 5000.0; c->reward_completion = 100.0;   // reward_function.py:9-11
+    c->reward_urgency_reduction = 20.0;               // uav_env.py:283
+    c->reward_movement = 10.0;                        // :285
+    c->penalty_revisit = -2.0; c->penalty_boundary = -50.0; c->penalty_collision = -10.0;      // reward_function.py:15-17
+    c->penalty_battery = -0.5;                        // uav_env.py:284
+    c->penalty_hover = -5.0; c->penalty_step = -0.5;  // reward_function.py:19-20
+    c->penalty_data_loss = -1.0;                      // uav_env.py:282
+    c->penalty_starvation = -1000.0; c->penalty_unvisited = -5000.0; c->penalty_starved = -1000.0;
+    c->starvation_cr_threshold = 0.20;                // reward_function.py:22-25
+    c->min_start_dist = 50.0; c->prox_eta = 2.0;      // dqn.py NAV_CONFIG
+    c->jain_weight = 0.5;                             // dqn.py:442
+    return UAVENV_OK;
+}
+
+static int obs_dim_of(const UavEnvConfig* c) {
+    int fps = c->include_sensor_positions ? 5 : 3;
+    int slots = c->pad_sensors > c->num_sensors ? c->pad_sensors : c->num_sensors;
+    return 3 + fps * slots;
+}
+extern "C" int uavenv_obs_dim(const UavEnvConfig* c) { return c ? obs_dim_of(c) : UAVENV_E_INVALID; }
+
+// Derived constants: each with the reference's own expression.
+static void derive_consts(const UavEnvConfig& c, Consts& k) {
+    std::memset(&k, 0, sizeof(k));
+    k.seed = c.seed;
+    k.rate = c.data_generation_rate; k.bmax = c.max_buffer_size; k.thr = c.rssi_threshold;
+    k.p_cycle = c.duty_cycle / 100.0;                                    // iot_sensors.py:105-107
+    k.maxb = c.max_battery; k.coll_dur = c.collection_duration;
+    k.sigma = c.shadowing_std_db; k.lambda = c.adr_lambda; k.one_minus_lambda = 1 - c.adr_lambda;
+    k.tx_power = c.tx_power_dbm; k.noise_floor = c.noise_floor_dbm; k.cap_thr = c.capture_threshold_db;
+    k.d_break = (4 * M_PI * c.sensor_height * c.uav_altitude) / c.wavelength;   // iot_sensors.py:174
+    k.c_fs = 20 * std::log10(c.freq_mhz); k.fspl_off = c.fspl_offset_db;        // :179
+    k.c_ht = 20 * std::log10(c.sensor_height); k.c_hr = 20 * std::log10(c.uav_altitude);   // :183
+    for (int i = 0; i < 4; i++) k.sf_thr[i] = c.sf_thresholds[i];
+    k.fill_lo = c.fill_lo; k.fill_span = c.fill_hi - c.fill_lo;
+    double time_step = 1.0;
+    k.e_move = (c.power_move * time_step) / 3600;                        // uav.py:176
+    k.e_coll = ((c.power_move * 0.5) * time_step) / 3600;                // uav.py:125,180
+    k.e_hover = (c.power_hover * c.collection_duration) / 3600;          // uav.py:204
+    k.used_hover = (c.power_hover / (60 * 60)) * c.collection_duration;  // uav.py:260-263, uav_env.py:530
+    k.alive_level = c.alive_fraction * c.max_battery;                    // uav.py:224
+    k.r_byte = c.reward_per_byte; k.r_new = c.reward_new_sensor; k.r_done = c.reward_completion;
+    k.r_urg = c.reward_urgency_reduction; k.r_move = c.reward_movement; k.p_revisit = c.penalty_revisit;
+    k.p_boundary = c.penalty_boundary; k.p_collision = c.penalty_collision; k.p_battery = c.penalty_battery;
+    k.p_hover = c.penalty_hover; k.p_step = c.penalty_step; k.p_loss = c.penalty_data_loss;
+    k.p_starvation = c.penalty_starvation; k.p_unvisited = c.penalty_unvisited; k.p_starved = c.penalty_starved;
+    k.cr_thr = c.starvation_cr_threshold;
+    k.min_start_dist = c.min_start_dist; k.prox_eta = c.prox_eta; k.jain_weight = c.jain_weight;
+    k.alt2 = (float)(c.uav_altitude * c.uav_altitude);                   // iot_sensors.py:164
+    k.max_steps = c.max_steps; k.fps = c.include_sensor_positions ? 5 : 3; k.obs_dim = obs_dim_of(&c);
+    k.max_tries = c.max_start_tries; k.use_ema = c.use_ema_adr; k.n_grid_choices = c.num_grid_choices;
+    k.flags = c.flags;
+    for (int i = 0; i < 8; i++) { k.gw[i] = c.grid_choices_w[i]; k.gh[i] = c.grid_choices_h[i]; }
+}
+
+static size_t field_elem_bytes(int field) {
+    switch (field) {
+        case UAVENV_F_POS_X: case UAVENV_F_POS_Y: return 4;
+        case UAVENV_F_BUFFER: case UAVENV_F_GEN: case UAVENV_F_TX: case UAVENV_F_LOST: case UAVENV_F_AVG_RSSI: return 8;
+        case UAVENV_F_FLAGS: return 4;
+        default: return 0;
+    }
+}
+static void* field_ptr(UavEnv* e, int field) {
+    switch (field) {
+        case UAVENV_F_POS_X: return e->ptrs.pos_x;   case UAVENV_F_POS_Y: return e->ptrs.pos_y;
+        case UAVENV_F_BUFFER: return e->ptrs.buffer; case UAVENV_F_GEN: return e->ptrs.gen;
+        case UAVENV_F_TX: return e->ptrs.tx;         case UAVENV_F_LOST: return e->ptrs.lost;
+        case UAVENV_F_AVG_RSSI: return e->ptrs.avg;  case UAVENV_F_FLAGS: return e->ptrs.flags;
+        case UAVENV_F_RECORD: return e->ptrs.rec;    case UAVENV_F_EPISODE_STATS: return e->ptrs.stats;
+        default: return nullptr;
+    }
+}
+extern "C" size_t uavenv_state_bytes(const UavEnv* e, int32_t field) {
+    if (!e) return 0;
+    if (field == UAVENV_F_RECORD) return (size_t)e->num_envs * sizeof(UavEnvRecord);
+    if (field == UAVENV_F_EPISODE_STATS) return (size_t)e->num_envs * sizeof(UavEnvEpisodeStats);
+    return (size_t)e->num_envs * (size_t)e->G * field_elem_bytes(field);
+}
+
+extern "C" int uavenv_create(const UavEnvConfig* cfg, int32_t num_envs, uint32_t env_index_base, int32_t device,
+                             UavEnv** out) {
+    if (!cfg || !out) return fail(nullptr, UAVENV_E_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(UavEnvConfig)) return fail(nullptr, UAVENV_E_INVALID, "UavEnvConfig.struct_size mismatch (ABI)");
+    if (num_envs <= 0) return fail(nullptr, UAVENV_E_INVALID, "num_envs must be positive");
+    if (cfg->num_sensors < 1 || cfg->num_sensors > 64) return fail(nullptr, UAVENV_E_INVALID, "num_sensors must be in 1..64");
+    if (cfg->grid_w < 1 || cfg->grid_h < 1) return fail(nullptr, UAVENV_E_INVALID, "grid must be positive");
+    if (cfg->num_grid_choices < 0 || cfg->num_grid_choices > 8) return fail(nullptr, UAVENV_E_INVALID, "num_grid_choices must be in 0..8");
+    static_assert(sizeof(UavEnvRecord) == 128, "UavEnvRecord must be 128 bytes");
+    UavEnv* e = new (std::nothrow) UavEnv();
+    if (!e) return fail(nullptr, UAVENV_E_ALLOC, "out of host memory");
+    e->cfg = *cfg;
+    e->num_envs = num_envs; e->env_index_base = env_index_base; e->device = device;
+    e->G = cfg->num_sensors <= 16 ? 16 : (cfg->num_sensors <= 32 ? 32 : 64);
+    const int per_block = kBlockThreads / e->G;
+    e->padded_envs = ((num_envs + per_block - 1) / per_block) * per_block;
+    derive_consts(e->cfg, e->consts);
+    if ((size_t)per_block * (size_t)e->consts.obs_dim * sizeof(float) > 64 * 1024) {
+        delete e; return fail(nullptr, UAVENV_E_INVALID, "observation row too large for the LDS staging tile");
+    }
+    auto bail = [&](int code, const std::string& m) { uavenv_destroy(e); return fail(nullptr, code, m); };
+    hipError_t st = hipSetDevice(device);
+    if (st != hipSuccess) return bail(UAVENV_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(st));
+    const size_t P = (size_t)e->padded_envs, S = P * (size_t)e->G;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t off = 0;
+    size_t o_px = off; off += al(S * 4);  size_t o_py = off; off += al(S * 4);
+    size_t o_b = off; off += al(S * 8);   size_t o_g = off; off += al(S * 8);  size_t o_t = off; off += al(S * 8);
+    size_t o_l = off; off += al(S * 8);   size_t o_a = off; off += al(S * 8);  size_t o_f = off; off += al(S * 4);
+    size_t o_r = off; off += al(P * sizeof(UavEnvRecord));
+    size_t o_s = off; off += al(P * sizeof(UavEnvEpisodeStats));
+    size_t o_st = off; off += 256;
+    e->block_bytes = off;
+    st = hipMalloc(&e->block, off);
+    if (st != hipSuccess) return bail(UAVENV_E_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(st));
+    char* base = (char*)e->block;
+    e->ptrs.pos_x = (float*)(base + o_px); e->ptrs.pos_y = (float*)(base + o_py);
+    e->ptrs.buffer = (double*)(base + o_b); e->ptrs.gen = (double*)(base + o_g); e->ptrs.tx = (double*)(base + o_t);
+    e->ptrs.lost = (double*)(base + o_l); e->ptrs.avg = (double*)(base + o_a); e->ptrs.flags = (uint32_t*)(base + o_f);
+    e->ptrs.rec = (UavEnvRecord*)(base + o_r); e->ptrs.stats = (UavEnvEpisodeStats*)(base + o_s);
+    e->ptrs.status = (uint32_t*)(base + o_st);
+    e->ptrs.step_tape = nullptr; e->ptrs.reset_tape = nullptr;
+    st = hipMemset(e->block, 0, off);
+    if (st != hipSuccess) return bail(UAVENV_E_HIP, std::string("hipMemset: ") + hipGetErrorString(st));
+    st = launch_init(e->G, e->padded_envs, e->consts, e->ptrs, env_index_base, cfg->grid_w, cfg->grid_h, cfg->num_sensors,
+                     (float)cfg->start_x, (float)cfg->start_y, nullptr);
+    if (st == hipSuccess) st = hipDeviceSynchronize();
+    if (st != hipSuccess) return bail(UAVENV_E_HIP, std::string("init kernel: ") + hipGetErrorString(st));
+    if (hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess)
+        return bail(UAVENV_E_HIP, "hipEventCreate failed");
+    *out = e;
+    return UAVENV_OK;
+}
+
+extern "C" int uavenv_destroy(UavEnv* e) {
+    if (!e) return UAVENV_OK;
+    if (e->block) (void)hipFree(e->block);
+    void* tmp[] = {e->h_actions_dev, e->h_obs_dev, e->h_rew_dev, e->h_done_dev, e->h_term_dev, e->h_mask_dev};
+    for (void* t : tmp) if (t) (void)hipFree(t);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    delete e;
+    return UAVENV_OK;
+}
+
+extern "C" const char* uavenv_last_error(const UavEnv* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+extern "C" int uavenv_num_envs(const UavEnv* e) { return e ? e->num_envs : UAVENV_E_INVALID; }
+extern "C" int uavenv_lane_stride(const UavEnv* e) { return e ? e->G : UAVENV_E_INVALID; }
+extern "C" int uavenv_env_obs_dim(const UavEnv* e) { return e ? e->consts.obs_dim : UAVENV_E_INVALID; }
+
+extern "C" int uavenv_set_env_params(UavEnv* e, const int32_t* gw, const int32_t* gh, const int32_t* ns) {
+    if (!e) return UAVENV_E_INVALID;
+    std::vector<UavEnvRecord> recs((size_t)e->num_envs);
+    HIP_TRY(e, hipMemcpy(recs.data(), e->ptrs.rec, recs.size() * sizeof(UavEnvRecord), hipMemcpyDeviceToHost));
+    for (int i = 0; i < e->num_envs; i++) {
+        if (gw) { if (gw[i] < 1) return fail(e, UAVENV_E_INVALID, "grid_w must be positive"); recs[i].grid_w = gw[i]; }
+        if (gh) { if (gh[i] < 1) return fail(e, UAVENV_E_INVALID, "grid_h must be positive"); recs[i].grid_h = gh[i]; }
+        if (ns) {
+            if (ns[i] < 1 || ns[i] > e->cfg.num_sensors) return fail(e, UAVENV_E_INVALID, "per-env num_sensors must be in 1..cfg.num_sensors");
+            recs[i].num_sensors = ns[i];
+        }
+    }
+    HIP_TRY(e, hipMemcpy(e->ptrs.rec, recs.data(), recs.size() * sizeof(UavEnvRecord), hipMemcpyHostToDevice));
+    return UAVENV_OK;
+}
+
+extern "C" int uavenv_set_positions(UavEnv* e, const float* px, const float* py) {
+    if (!e || !px || !py) return UAVENV_E_INVALID;
+    size_t bytes = (size_t)e->num_envs * e->G * 4;
+    HIP_TRY(e, hipMemcpy(e->ptrs.pos_x, px, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(e->ptrs.pos_y, py, bytes, hipMemcpyHostToDevice));
+    return UAVENV_OK;
+}
+
+extern "C" int uavenv_set_seed(UavEnv* e, uint64_t seed) {
+    if (!e) return UAVENV_E_INVALID;
+    e->cfg.seed = seed; e->consts.seed = seed;
+    return UAVENV_OK;
+}
+
+extern "C" int uavenv_set_grid_choices(UavEnv* e, int32_t count, const int32_t* w, const int32_t* h) {
+    if (!e || count < 0 || count > 8 || (count > 0 && (!w || !h))) return UAVENV_E_INVALID;
+    e->cfg.num_grid_choices = count; e->consts.n_grid_choices = count;
+    for (int i = 0; i < count; i++) {
+        if (w[i] < 1 || h[i] < 1) return fail(e, UAVENV_E_INVALID, "grid choice must be positive");
+        e->cfg.grid_choices_w[i] = e->consts.gw[i] = w[i];
+        e->cfg.grid_choices_h[i] = e->consts.gh[i] = h[i];
+    }
+    return UAVENV_OK;
+}
+
+extern "C" int uavenv_set_noise_tape(UavEnv* e, const float* step_tape_dev, const float* reset_tape_dev) {
+    if (!e) return UAVENV_E_INVALID;
+    e->ptrs.step_tape = step_tape_dev; e->ptrs.reset_tape = reset_tape_dev;
+    return UAVENV_OK;
+}
+
+extern "C" int uavenv_dump_noise(UavEnv* e, float* step_tape_out, float* reset_tape_out, void* stream) {
+    if (!e) return UAVENV_E_INVALID;
+    HIP_TRY(e, launch_dump_noise(e->G, e->padded_envs, e->consts, e->ptrs, step_tape_out, reset_tape_out, e->num_envs,
+                                 (hipStream_t)stream));
+    return UAVENV_OK;
+}
+
+extern "C" int uavenv_reset(UavEnv* e, const uint8_t* mask_dev, float* obs_out_dev, void* stream) {
+    if (!e) return UAVENV_E_INVALID;
+    ResetArgs a{mask_dev, obs_out_dev, e->num_envs};
+    HIP_TRY(e, launch_reset(e->G, e->padded_envs, e->consts, e->ptrs, a, (hipStream_t)stream));
+    return UAVENV_OK;
+}
+
+static int step_common(UavEnv* e, const int32_t* actions, int32_t* actions_out, float* obs, double* rew, float* rew32,
+                       uint8_t* done, float* term, void* stream) {
+    if (!e) return UAVENV_E_INVALID;
+    StepArgs a{actions, actions_out, obs, rew, rew32, done, term, e->num_envs};
+    HIP_TRY(e, launch_step(e->G, e->padded_envs, e->consts, e->ptrs, a, (hipStream_t)stream));
+    return UAVENV_OK;
+}
+
+extern "C" int uavenv_step(UavEnv* e, const int32_t* actions_dev, float* obs, double* rew, float* rew32, uint8_t* done,
+                           float* term, void* stream) {
+    if (!e || !actions_dev) return e ? fail(e, UAVENV_E_INVALID, "actions_dev is NULL") : UAVENV_E_INVALID;
+    return step_common(e, actions_dev, nullptr, obs, rew, rew32, done, term, stream);
+}
+
+extern "C" int uavenv_step_random(UavEnv* e, int32_t* actions_out, float* obs, double* rew, float* rew32, uint8_t* done,
+                                  float* term, void* stream) {
+    return step_common(e, nullptr, actions_out, obs, rew, rew32, done, term, stream);
+}
+
+extern "C" int uavenv_get_state(UavEnv* e, int32_t field, void* dst, size_t bytes, int32_t dst_on_device, void* stream) {
+    if (!e || !dst) return UAVENV_E_INVALID;
+    void* src = field_ptr(e, field);
+    if (!src) return fail(e, UAVENV_E_INVALID, "unknown state field");
+    if (bytes != uavenv_state_bytes(e, field)) return fail(e, UAVENV_E_INVALID, "state field size mismatch");
+    HIP_TRY(e, hipMemcpyAsync(dst, src, bytes, dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, (hipStream_t)stream));
+    if (!dst_on_device) HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream));
+    return UAVENV_OK;
+}
+
+extern "C" int uavenv_set_state(UavEnv* e, int32_t field, const void* src, size_t bytes, int32_t src_on_device, void* stream) {
+    if (!e || !src) return UAVENV_E_INVALID;
+    void* dst = field_ptr(e, field);
+    if (!dst) return fail(e, UAVENV_E_INVALID, "unknown state field");
+    if (bytes != uavenv_state_bytes(e, field)) return fail(e, UAVENV_E_INVALID, "state field size mismatch");
+    HIP_TRY(e, hipMemcpyAsync(dst, src, bytes, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, (hipStream_t)stream));
+    if (!src_on_device) HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream));
+    return UAVENV_OK;
+}
+
+static int ensure_host_staging(UavEnv* e) {
+    if (e->h_obs_dev) return UAVENV_OK;
+    size_t E = (size_t)e->num_envs, D = (size_t)e->consts.obs_dim;
+    HIP_TRY(e, hipMalloc((void**)&e->h_actions_dev, E * 4));
+    HIP_TRY(e, hipMalloc((void**)&e->h_obs_dev, E * D * 4));
+    HIP_TRY(e, hipMalloc((void**)&e->h_rew_dev, E * 8));
+    HIP_TRY(e, hipMalloc((void**)&e->h_done_dev, E));
+    HIP_TRY(e, hipMalloc((void**)&e->h_term_dev, E * D * 4));
+    HIP_TRY(e, hipMalloc((void**)&e->h_mask_dev, E));
+    return UAVENV_OK;
+}
+
+static int check_status(UavEnv* e) {
+    uint32_t st = 0;
+    HIP_TRY(e, hipMemcpy(&st, e->ptrs.status, 4, hipMemcpyDeviceToHost));
+    if (st & 1u) {
+        HIP_TRY(e, hipMemset(e->ptrs.status, 0, 4));
+        return fail(e, UAVENV_E_ACTION, "Invalid action: outside 0..4 (uav_env.py:468)");
+    }
+    return UAVENV_OK;
+}
+
+extern "C" int uavenv_reset_host(UavEnv* e, const uint8_t* mask, float* obs_out) {
+    if (!e || !obs_out) return UAVENV_E_INVALID;
+    int rc = ensure_host_staging(e); if (rc) return rc;
+    size_t E = (size_t)e->num_envs, D = (size_t)e->consts.obs_dim;
+    if (mask) HIP_TRY(e, hipMemcpy(e->h_mask_dev, mask, E, hipMemcpyHostToDevice));
+    if (mask) HIP_TRY(e, hipMemcpy(e->h_obs_dev, obs_out, E * D * 4, hipMemcpyHostToDevice));   // keep unmasked rows
+    rc = uavenv_reset(e, mask ? e->h_mask_dev : nullptr, e->h_obs_dev, nullptr); if (rc) return rc;
+    HIP_TRY(e, hipMemcpy(obs_out, e->h_obs_dev, E * D * 4, hipMemcpyDeviceToHost));
+    return UAVENV_OK;
+}
+
+extern "C" int uavenv_step_host(UavEnv* e, const int32_t* actions, float* obs_out, double* reward_out, uint8_t* done_out,
+                                float* terminal_obs_out) {
+    if (!e || !actions || !obs_out) return UAVENV_E_INVALID;
+    int rc = ensure_host_staging(e); if (rc) return rc;
+    size_t E = (size_t)e->num_envs, D = (size_t)e->consts.obs_dim;
+    for (size_t i = 0; i < E; i++)
+        if (actions[i] < 0 || actions[i] > 4) return fail(e, UAVENV_E_ACTION, "Invalid action: outside 0..4 (uav_env.py:468)");
+    HIP_TRY(e, hipMemcpy(e->h_actions_dev, actions, E * 4, hipMemcpyHostToDevice));
+    rc = uavenv_step(e, e->h_actions_dev, e->h_obs_dev, e->h_rew_dev, nullptr, e->h_done_dev,
+                     terminal_obs_out ? e->h_term_dev : nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(e, hipMemcpy(obs_out, e->h_obs_dev, E * D * 4, hipMemcpyDeviceToHost));
+    if (reward_out) HIP_TRY(e, hipMemcpy(reward_out, e->h_rew_dev, E * 8, hipMemcpyDeviceToHost));
+    if (done_out) HIP_TRY(e, hipMemcpy(done_out, e->h_done_dev, E, hipMemcpyDeviceToHost));
+    if (terminal_obs_out) HIP_TRY(e, hipMemcpy(terminal_obs_out, e->h_term_dev, E * D * 4, hipMemcpyDeviceToHost));
+    return check_status(e);
+}
+
+extern "C" int uavenv_time_steps(UavEnv* e, int32_t steps, float* obs, double* rew, uint8_t* done, void* stream,
+                                 float* avg_ms) {
+    if (!e || steps <= 0 || !avg_ms) return UAVENV_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(e, hipEventRecord(e->ev0, s));
+    for (int i = 0; i < steps; i++) {
+        int rc = step_common(e, nullptr, nullptr, obs, rew, nullptr, done, nullptr, stream);
+        if (rc) return rc;
+    }
+    HIP_TRY(e, hipEventRecord(e->ev1, s));
+    HIP_TRY(e, hipEventSynchronize(e->ev1));
+    float ms = 0.f;
+    HIP_TRY(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    *avg_ms = ms / (float)steps;
+    return UAVENV_OK;
+}

@@ -1,0 +1,76 @@
+// uavenv_internal.h -- structures shared by the kernels (uavenv_kernels.hip) and the C ABI
+// (uavenv_capi.hip).  Not part of the public boundary (that is include/uavenv.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/uavenv.h"
+
+namespace uavenv {
+
+constexpr int kBlockThreads = 256;          // 4 wavefronts per workgroup
+
+// flag word per sensor (UAVENV_F_FLAGS)
+constexpr uint32_t kSfMask = 15u, kAvgValid = 16u, kVisited = 32u, kDataCollected = 64u;
+
+// Host-precomputed constants, passed to every kernel BY VALUE (kernarg segment -> SGPRs).
+// Each derived value is computed on the host with the reference's own expression, cited.
+struct Consts {
+    uint64_t seed;
+    double rate, bmax, thr, p_cycle, maxb, coll_dur;
+    double sigma, lambda, one_minus_lambda, tx_power, noise_floor, cap_thr;
+    double d_break;        // iot_sensors.py:174  (4*pi*ht*hr)/0.345
+    double c_fs;           // iot_sensors.py:179  20*log10(868)
+    double fspl_off;       //                     28
+    double c_ht, c_hr;     // iot_sensors.py:183  20*log10(ht), 20*log10(hr)
+    double sf_thr[4];
+    double fill_lo, fill_span;
+    double e_move, e_coll, e_hover;   // uav.py:176,180,204  (P*t)/3600
+    double used_hover;                // uav_env.py:530      (P_hover/3600)*duration
+    double alive_level;               // uav.py:224          0.02*max_battery
+    double r_byte, r_new, r_done, r_urg, r_move, p_revisit, p_boundary, p_collision, p_battery,
+           p_hover, p_step, p_loss, p_starvation, p_unvisited, p_starved, cr_thr;
+    double min_start_dist, prox_eta, jain_weight;
+    float  alt2;                      // iot_sensors.py:164  altitude**2 as float32
+    int32_t max_steps, fps, obs_dim, max_tries, use_ema, n_grid_choices;
+    uint32_t flags;
+    int32_t gw[8], gh[8];
+};
+
+struct Ptrs {
+    float *pos_x, *pos_y;
+    double *buffer, *gen, *tx, *lost, *avg;
+    uint32_t* flags;
+    UavEnvRecord* rec;
+    UavEnvEpisodeStats* stats;
+    const float* step_tape;     // [E][6][G] or nullptr
+    const float* reset_tape;    // [E][3][G] or nullptr
+    uint32_t* status;           // device word: OR of per-env status bits
+};
+
+struct StepArgs {
+    const int32_t* actions;     // nullptr => in-kernel random policy
+    int32_t* actions_out;
+    float* obs;
+    double* reward;
+    float* reward32;
+    uint8_t* done;
+    float* term_obs;
+    int32_t num_envs;           // E (arrays are padded to a whole number of workgroups)
+};
+
+struct ResetArgs {
+    const uint8_t* mask;
+    float* obs;
+    int32_t num_envs;
+};
+
+// launchers (uavenv_kernels.hip)
+hipError_t launch_init(int G, int padded_envs, const Consts& c, const Ptrs& p, uint32_t env_index_base,
+                       int32_t grid_w, int32_t grid_h, int32_t n, float start_x, float start_y, hipStream_t s);
+hipError_t launch_reset(int G, int padded_envs, const Consts& c, const Ptrs& p, const ResetArgs& a, hipStream_t s);
+hipError_t launch_step(int G, int padded_envs, const Consts& c, const Ptrs& p, const StepArgs& a, hipStream_t s);
+hipError_t launch_dump_noise(int G, int padded_envs, const Consts& c, const Ptrs& p, float* step_tape,
+                             float* reset_tape, int32_t num_envs, hipStream_t s);
+
+}  // namespace uavenv

@@ -1,0 +1,742 @@
+// uavenv_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4) for the batched UAV-IoT
+// environment reset()/step() hot path.
+//
+// Mapping: one lane GROUP of G in {16,32,64} lanes of a 64-wide wavefront owns one environment
+// instance, one lane owns one sensor.  64/G environments share a wavefront, 256/G a workgroup.
+// Per-sensor state is SoA [E][G] in HBM (every wave-load is one contiguous 256..512 B row per
+// array), lives in VGPRs for the whole step, and is written back once.  Reductions over sensors
+// (data-loss sum, Capture-Effect top-2, variance, urgency sums, Jain's sums) are wavefront
+// butterfly shuffles / ballots restricted to the group.  The observation row is transposed
+// through LDS so the [E][obs_dim] float32 write is coalesced.  No MFMA: the path is elementwise +
+// short reductions.
+//
+// Reference being replaced (paths relative to /root/reference/src/):
+//   environment/uav_env.py       step :429-488, _execute_move_action :494-516,
+//                                _execute_collect_action :518-632, _get_observation :638-674,
+//                                reset :400-427
+//   environment/iot_sensors.py   step :114-125, collect_data :127-145, calculate_rssi :147-197,
+//                                get_success_probability :202-212, update_spreading_factor :223-259
+//   environment/uav.py           move :127-185, hover :187-206, is_alive :208-224
+//   rewards/reward_function.py   :46-128
+//   agents/dqn/dqn.py            DomainRandEnv reset/step :301-451 (optional flags)
+//
+// Compiled with -ffp-contract=off: numpy never fuses a*b+c, and the float64 state must follow
+// the reference's operation order to stay within the 1e-5 parity contract over 2100-step episodes.
+#include "uavenv_internal.h"
+#include "uavenv_noise.h"
+
+namespace uavenv {
+
+// ---------------------------------------------------------------------------------------------
+// lane-group primitives (G lanes of a wave64)
+// ---------------------------------------------------------------------------------------------
+template <int G> __device__ __forceinline__ int group_base() { return (int)(threadIdx.x & 63u) & ~(G - 1); }
+template <int G> __device__ __forceinline__ int group_lane() { return (int)(threadIdx.x & (unsigned)(G - 1)); }
+
+template <int G> __device__ __forceinline__ double gsum(double v) {
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+template <int G> __device__ __forceinline__ double gmax(double v) {
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) { double o = __shfl_xor(v, m, 64); v = o > v ? o : v; }
+    return v;
+}
+template <int G> __device__ __forceinline__ float gmin_f32(float v) {
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) { float o = __shfl_xor(v, m, 64); v = o < v ? o : v; }
+    return v;
+}
+// ballot restricted to this lane's group, shifted so bit k = group lane k
+template <int G> __device__ __forceinline__ uint64_t gballot(bool pred) {
+    uint64_t b = __ballot(pred);
+    if (G == 64) return b;
+    return (b >> group_base<G>()) & ((1ull << (G & 63)) - 1ull);
+}
+template <int G> __device__ __forceinline__ bool gany(bool pred) { return gballot<G>(pred) != 0ull; }
+template <int G, typename T> __device__ __forceinline__ T gshfl(T v, int src) { return __shfl(v, group_base<G>() + src, 64); }
+
+// numpy float32 add.reduce order (pairwise sum, n <= 64 < PW_BLOCKSIZE): 8 strided accumulators
+// combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then a sequential tail; plain loop for n < 8.
+// Reproduces np.sum(np.maximum(0, before - after)) at uav_env.py:601 bit for bit.
+template <int G> __device__ __forceinline__ float np_sum_f32(float a, int n) {
+    const int gl = group_lane<G>();
+    const int n8 = n - (n & 7);
+    float r = a;
+#pragma unroll
+    for (int k = 1; k < G / 8; k++) {
+        float v = gshfl<G>(a, (gl + 8 * k) & (G - 1));
+        if (gl + 8 * k < n8) r += v;
+    }
+    r += __shfl_xor(r, 1, 64);
+    r += __shfl_xor(r, 2, 64);
+    r += __shfl_xor(r, 4, 64);
+    float tree = gshfl<G>(r, 0);
+    float res = (n < 8) ? 0.0f : tree;
+    const int start = (n < 8) ? 0 : n8;
+#pragma unroll
+    for (int t = 0; t < 7; t++) {
+        int i = start + t;
+        float v = gshfl<G>(a, i & (G - 1));
+        if (i < n) res += v;
+    }
+    return res;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LoRa tables: iot_sensors.py:13-20 (bytes/s), :22-29 (required SNR dB); uav_env.py:647 (link quality)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double sf_data_rate(uint32_t sf) {
+    return sf == 7 ? 5470 / 8.0 : sf == 8 ? 3125 / 8.0 : sf == 9 ? 1760 / 8.0 : sf == 10 ? 980 / 8.0
+         : sf == 11 ? 440 / 8.0 : 250 / 8.0;
+}
+__device__ __forceinline__ double sf_required_snr(uint32_t sf) {
+    return sf == 7 ? -6.0 : sf == 8 ? -9.0 : sf == 9 ? -12.0 : sf == 10 ? -15.0 : sf == 11 ? -17.5
+         : sf == 12 ? -20.0 : 7.5;
+}
+__device__ __forceinline__ double sf_link_quality(uint32_t sf) {
+    return sf == 7 ? 1.0 : sf == 8 ? 0.8 : sf == 9 ? 0.6 : sf == 10 ? 0.4 : sf == 11 ? 0.2 : 0.1;
+}
+
+// iot_sensors.py:147-189: deterministic RSSI.  Distances and 20*log10f(d) in float32, sums in
+// float64, exactly the reference's mix.  log10 of the float32 distance is evaluated in float64 and
+// rounded once, i.e. the correctly rounded float32 log10 (the reference's own np.log10(float32) is
+// platform dependent at the 1-ulp level; see oracle/uavenv_oracle.h).
+__device__ __forceinline__ double rssi_deterministic(const Consts& c, float ux, float uy, float sx, float sy) {
+    float dx = (ux - sx) * 10.0f;
+    float dy = (uy - sy) * 10.0f;
+    float ground = sqrt_rn(dx * dx + dy * dy);
+    float d = sqrt_rn(ground * ground + c.alt2);
+    float l10 = (float)log10((double)d);
+    double path_loss;
+    if ((double)d < c.d_break) {
+        float t = 20.0f * l10;
+        path_loss = ((double)t + c.c_fs) - c.fspl_off;
+    } else {
+        float t = 40.0f * l10;
+        path_loss = ((double)t - c.c_ht) - c.c_hr;
+    }
+    return c.tx_power - path_loss;
+}
+
+// iot_sensors.py:223-259 update_spreading_factor (EMA-ADR), state in (avg, flags)
+__device__ __forceinline__ void adr_update(const Consts& c, double cur, double& avg, uint32_t& flags) {
+    double nv = cur;
+    if ((flags & kAvgValid) && c.use_ema) nv = (c.lambda * cur) + (c.one_minus_lambda * avg);
+    avg = nv;
+    uint32_t sf = flags & kSfMask;
+    if (nv > c.sf_thr[0]) sf = 7;
+    else if (nv > c.sf_thr[1]) sf = 9;
+    else if (nv > c.sf_thr[2]) sf = 11;
+    else if (nv > c.sf_thr[3]) sf = 12;          // else: sticky (iot_sensors.py:251-255)
+    flags = (flags & ~kSfMask) | sf | kAvgValid;
+}
+
+// uav_env.py:376-384 _calculate_urgency
+__device__ __forceinline__ double calc_urgency(const Consts& c, double b, double gen, double lost) {
+    double util = b / c.bmax;
+    double loss_rate = gen > 0 ? lost / gen : 0.0;
+    double u = util * (1.0 + loss_rate * 10.0);
+    return u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
+}
+
+// per-lane sensor registers
+struct Sensor {
+    double b, gen, tx, lost, avg;
+    float sx, sy;
+    uint32_t flags;
+};
+
+template <int G> __device__ __forceinline__ void load_sensor(const Ptrs& p, size_t idx, Sensor& s) {
+    s.sx = p.pos_x[idx]; s.sy = p.pos_y[idx];
+    s.b = p.buffer[idx]; s.gen = p.gen[idx]; s.tx = p.tx[idx]; s.lost = p.lost[idx]; s.avg = p.avg[idx];
+    s.flags = p.flags[idx];
+}
+template <int G> __device__ __forceinline__ void store_sensor(const Ptrs& p, size_t idx, const Sensor& s, bool with_pos) {
+    if (with_pos) { p.pos_x[idx] = s.sx; p.pos_y[idx] = s.sy; }
+    p.buffer[idx] = s.b; p.gen[idx] = s.gen; p.tx[idx] = s.tx; p.lost[idx] = s.lost; p.avg[idx] = s.avg;
+    p.flags[idx] = s.flags;
+}
+
+// dqn.py:406-412 distance to the nearest sensor that still has data (float32 norm), 0 if none
+template <int G> __device__ __forceinline__ double dist_nearest_with_data(const Sensor& s, bool act, float ux, float uy) {
+    float dx = s.sx - ux, dy = s.sy - uy;
+    float d = sqrt_rn(dx * dx + dy * dy);
+    bool has = act && s.b > 0;
+    float m = gmin_f32<G>(has ? d : __builtin_inff());
+    return gany<G>(has) ? (double)m : 0.0;
+}
+
+// dqn.py:446-451 Jain's index over r_i = 100*tx_i/gen_i (gen_i > 0); also returns the population
+// std of the rates (dqn.py:324 fairness_std)
+template <int G> __device__ __forceinline__ double jains_index(const Sensor& s, bool act, double* std_out) {
+    bool ok = act && s.gen > 0;
+    double r = ok ? (s.tx / s.gen) * 100 : 0.0;
+    double s1 = gsum<G>(r), s2 = gsum<G>(r * r);
+    int cnt = __popcll(gballot<G>(ok));
+    if (std_out) {
+        double mean = cnt > 0 ? s1 / cnt : 0.0;
+        double dv = ok ? (r - mean) * (r - mean) : 0.0;
+        double var = cnt > 0 ? gsum<G>(dv) / cnt : 0.0;
+        *std_out = sqrt(var);
+    }
+    return (cnt > 0 && s2 > 0) ? (s1 * s1) / (cnt * s2) : 1.0;
+}
+
+// uav_env.py:638-674 _get_observation for one environment group.  SIDE EFFECT on the lane's
+// sensor: advances the ADR EMA with slot zD, then draws the in-range sample zE.  The row is staged
+// in LDS (stride-fps writes are bank-conflict free: fps in {3,5} is coprime to 32) and written
+// out as contiguous dwords.  `enable` masks whole groups (a wave may hold groups that do not
+// rebuild); `dst` may be nullptr (row computed for its side effects, not stored).
+template <int G>
+__device__ __forceinline__ void observe(const Consts& c, Sensor& s, const UavEnvRecord& r, bool act, bool enable,
+                                        double det, float zD, float zE, float* dst, float* lds_row) {
+    const int gl = group_lane<G>();
+    const int n = r.num_sensors;
+    double W = (double)r.grid_w, H = (double)r.grid_h;
+    double ux = (double)r.uav_x, uy = (double)r.uav_y;
+    float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f, f4 = 0.f;
+    if (enable && act) {
+        double urgency = calc_urgency(c, s.b, s.gen, s.lost);                 // :652 (before the ADR update)
+        adr_update(c, det + c.sigma * (double)zD, s.avg, s.flags);           // :654
+        bool in_range = (det + c.sigma * (double)zE) >= c.thr;               // :658, iot_sensors.py:214-219
+        f0 = (float)(s.b / c.bmax);
+        f1 = (float)urgency;
+        f2 = (float)(in_range ? sf_link_quality(s.flags & kSfMask) : 0.0);
+        if (c.fps == 5) {                                                     // :668-672
+            f3 = (float)(((double)s.sx - ux) / W);
+            f4 = (float)(((double)s.sy - uy) / H);
+        }
+    }
+    if (enable) {
+        // zero the padded tail [3 + fps*n, obs_dim)  (dqn.py:286-298)
+        for (int k = 3 + c.fps * n + gl; k < c.obs_dim; k += G) lds_row[k] = 0.0f;
+        if (gl == 0) {
+            lds_row[0] = (float)(ux / W);
+            lds_row[1] = (float)(uy / H);
+            lds_row[2] = (float)(r.battery / c.maxb);
+        }
+        if (act) {
+            float* q = lds_row + 3 + c.fps * gl;
+            q[0] = f0; q[1] = f1; q[2] = f2;
+            if (c.fps == 5) { q[3] = f3; q[4] = f4; }
+        }
+    }
+    // LDS hand-off inside one wavefront: wave-scope release/acquire is sufficient (and a workgroup
+    // barrier would be illegal here: the second observe() of a step runs under wave-uniform, not
+    // workgroup-uniform, control flow).
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (enable && dst != nullptr)
+        for (int k = gl; k < c.obs_dim; k += G) dst[k] = lds_row[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Noise for one step of one lane: Philox, or the injected tape (parity testing)
+struct StepNoise { float zA, zB, u, zC, zD, zE; };
+
+template <int G>
+__device__ __forceinline__ void draw_step_noise(const Consts& c, const Ptrs& p, const UavEnvRecord& r, size_t env,
+                                                bool in_batch, uint32_t step, bool need_collect, StepNoise& z) {
+    const int gl = group_lane<G>();
+    if (p.step_tape != nullptr) {                      // kernel-uniform
+        z.zA = z.zB = z.zC = z.zD = z.zE = 0.f; z.u = 1.f;
+        if (in_batch) {                                // the tape has no rows for the padding environments
+            const float* t = p.step_tape + env * (size_t)(UAVENV_TAPE_STEP_SLOTS * G) + gl;
+            z.zA = t[0 * G]; z.zB = t[1 * G]; z.u = t[2 * G]; z.zC = t[3 * G]; z.zD = t[4 * G]; z.zE = t[5 * G];
+        }
+        return;
+    }
+    Words4 w = noise_words(c.seed, r.env_index, r.episode, step, (uint32_t)gl, 0);
+    normal_pair(w.w0, w.w1, z.zD, z.zE);
+    z.u = u24(w.w2);
+    z.zA = z.zB = z.zC = 0.f;
+    if (need_collect) {                       // wave-uniform
+        Words4 v = noise_words(c.seed, r.env_index, r.episode, step, (uint32_t)gl, 1);
+        float spare;
+        normal_pair(v.w0, v.w1, z.zA, z.zB);
+        normal_pair(v.w2, v.w3, z.zC, spare);
+    }
+}
+
+// uav_env.py:400-427 reset (+ iot_sensors.py:305-321, uav.py:241-258; DomainRandEnv.reset
+// dqn.py:301-373 under the flags) for the groups with `rs` set.  Leaves the new episode's sensor
+// registers in `s`, the record in `r`, and returns (zD, zE) of the reset observation.
+template <int G>
+__device__ __forceinline__ void reset_group(const Consts& c, const Ptrs& p, Sensor& s, UavEnvRecord& r, size_t env,
+                                            bool in_batch, bool rs, bool draw_layout, float& zD, float& zE) {
+    const int gl = group_lane<G>();
+    if (!rs) return;                                   // group-uniform; no cross-lane ops skipped below
+    r.episode += 1u;
+    const uint32_t ep = r.episode;
+    Words4 w = noise_words(c.seed, r.env_index, ep, 0u, (uint32_t)gl, 2);
+    if ((c.flags & UAVENV_FLAG_RANDOM_LAYOUT) && c.n_grid_choices > 0) {          // dqn.py:334
+        Words4 w0 = noise_words(c.seed, r.env_index, ep, 0u, 0u, 2);
+        int g = (int)(((uint64_t)w0.w3 * (uint32_t)c.n_grid_choices) >> 32);
+        r.grid_w = c.gw[g]; r.grid_h = c.gh[g];
+    }
+    float fill_u = u24(w.w0);
+    if (p.reset_tape != nullptr) {
+        fill_u = 0.f; zD = 0.f; zE = 0.f;
+        if (in_batch) {
+            const float* t = p.reset_tape + env * (size_t)(UAVENV_RTAPE_SLOTS * G) + gl;
+            fill_u = t[0 * G]; zD = t[1 * G]; zE = t[2 * G];
+        }
+    } else {
+        Words4 v = noise_words(c.seed, r.env_index, ep, 0u, (uint32_t)gl, 0);
+        normal_pair(v.w0, v.w1, zD, zE);
+    }
+    if (draw_layout) {                                                             // uav_env.py:366-374 / dqn.py:342-344
+        s.sx = u24(w.w1) * (float)r.grid_w;
+        s.sy = u24(w.w2) * (float)r.grid_h;
+    }
+    double fill = c.fill_lo + c.fill_span * (double)fill_u;                        // uav_env.py:410
+    double clipped = fill < 0.0 ? 0.0 : (fill > 1.0 ? 1.0 : fill);
+    s.b = c.bmax * clipped;                                                        // iot_sensors.py:308
+    s.gen = s.b;                                                                   // :316
+    s.tx = 0.0; s.lost = 0.0; s.avg = 0.0;                                         // :311,317-318
+    s.flags = (s.flags & kDataCollected) | 12u;                                    // :309 SF12; visited cleared (uav_env.py:416)
+    if (c.flags & UAVENV_FLAG_RANDOM_LAYOUT) { s.b = 0.0; s.gen = 0.0; s.flags = 12u; }   // dqn.py:346-360 fresh sensors
+    r.battery = c.maxb;                                                            // uav.py:257
+    r.current_step = 0; r.total_reward = 0.0; r.total_data_collected = 0.0;        // uav_env.py:413-415
+    r.last_step_bytes = 0.0; r.capture_triggers = 0; r.boundary_hits = 0;          // :419-422
+    r.edge_steps = 0; r.collisions_total = 0; r.first_full_coverage_step = -1;
+    r.episode_return = 0.0;
+}
+
+// dqn.py:375-403 _sample_far_start: rejection-sample a start >= min_start_dist from every sensor,
+// falling back to the furthest candidate.  Candidates from Philox call 4 (lane field = try).
+template <int G>
+__device__ __forceinline__ void far_start(const Consts& c, const Sensor& s, UavEnvRecord& r, bool act, bool rs) {
+    double W = (double)r.grid_w, H = (double)r.grid_h;
+    float best_x = r.start_x, best_y = r.start_y, best_d = -1.0f;
+    bool searching = rs;
+    for (int t = 0; t < c.max_tries; t++) {
+        if (!__any(searching)) break;
+        Words4 w = noise_words(c.seed, r.env_index, r.episode, 0u, (uint32_t)t, 4);
+        float cx = (float)(0.05 * W + (0.95 * W - 0.05 * W) * (double)u24(w.w0));
+        float cy = (float)(0.05 * H + (0.95 * H - 0.05 * H) * (double)u24(w.w1));
+        float dx = cx - s.sx, dy = cy - s.sy;
+        float d = sqrt_rn(dx * dx + dy * dy);
+        float dmin = gmin_f32<G>(act ? d : __builtin_inff());
+        if (searching) {
+            if (dmin > best_d) { best_d = dmin; best_x = cx; best_y = cy; }
+            if ((double)dmin >= c.min_start_dist) { best_x = cx; best_y = cy; searching = false; }
+        }
+    }
+    if (rs) { r.start_x = best_x; r.start_y = best_y; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// init kernel: records + (optionally) Philox sensor layouts, no episode started
+// ---------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(kBlockThreads) void uav_init_kernel(Consts c, Ptrs p, uint32_t env_index_base,
+                                                                 int32_t grid_w, int32_t grid_h, int32_t n,
+                                                                 float start_x, float start_y) {
+    const int gl = group_lane<G>();
+    const size_t env = (size_t)blockIdx.x * (kBlockThreads / G) + threadIdx.x / G;
+    const size_t idx = env * G + gl;
+    uint32_t gidx = env_index_base + (uint32_t)env;
+    Words4 w = noise_words(c.seed, gidx, 0xFFFFFFFFu, 0u, (uint32_t)gl, 2);
+    p.pos_x[idx] = u24(w.w1) * (float)grid_w;
+    p.pos_y[idx] = u24(w.w2) * (float)grid_h;
+    p.buffer[idx] = 0.0; p.gen[idx] = 0.0; p.tx[idx] = 0.0; p.lost[idx] = 0.0; p.avg[idx] = 0.0;
+    p.flags[idx] = 12u;
+    if (gl == 0) {
+        UavEnvRecord r;
+        r.battery = c.maxb; r.total_reward = 0.0; r.total_data_collected = 0.0; r.last_step_bytes = 0.0;
+        r.prev_dist_nearest = 0.0; r.episode_return = 0.0;
+        r.uav_x = start_x; r.uav_y = start_y; r.start_x = start_x; r.start_y = start_y;
+        r.current_step = 0; r.episode = 0xFFFFFFFFu;
+        r.capture_triggers = 0; r.boundary_hits = 0; r.edge_steps = 0; r.collisions_total = 0;
+        r.first_full_coverage_step = -1;
+        r.grid_w = grid_w; r.grid_h = grid_h; r.num_sensors = n;
+        r.env_index = gidx; r.status = 0u;
+        r.reserved[0] = r.reserved[1] = r.reserved[2] = r.reserved[3] = 0u;
+        p.rec[env] = r;
+        UavEnvEpisodeStats st = {};
+        p.stats[env] = st;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// reset kernel
+// ---------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(kBlockThreads) void uav_reset_kernel(Consts c, Ptrs p, ResetArgs a) {
+    extern __shared__ float lds[];
+    const int gl = group_lane<G>();
+    const size_t env = (size_t)blockIdx.x * (kBlockThreads / G) + threadIdx.x / G;
+    const size_t idx = env * G + gl;
+    float* lds_row = lds + (threadIdx.x / G) * c.obs_dim;
+
+    UavEnvRecord r = p.rec[env];
+    Sensor s;
+    load_sensor<G>(p, idx, s);
+    const bool in_batch = env < (size_t)a.num_envs;
+    bool rs = true;
+    if (a.mask != nullptr) rs = in_batch && a.mask[env] != 0;
+    const bool act = gl < r.num_sensors;
+
+    float zD = 0.f, zE = 0.f;
+    const bool draw_layout = (c.flags & UAVENV_FLAG_RANDOM_LAYOUT) != 0;
+    reset_group<G>(c, p, s, r, env, in_batch, rs, draw_layout, zD, zE);
+    if (c.flags & UAVENV_FLAG_FAR_START) far_start<G>(c, s, r, act, rs);
+    if (rs) { r.uav_x = r.start_x; r.uav_y = r.start_y; }                         // uav.py:256, dqn.py:364-365
+    double det = rssi_deterministic(c, r.uav_x, r.uav_y, s.sx, s.sy);
+    float* dst = (in_batch && a.obs != nullptr) ? a.obs + env * (size_t)c.obs_dim : nullptr;
+    observe<G>(c, s, r, act, rs, det, zD, zE, dst, lds_row);                       // uav_env.py:427
+    if (c.flags & UAVENV_FLAG_PROX_SHAPING) {
+        double d0 = dist_nearest_with_data<G>(s, act, r.uav_x, r.uav_y);           // dqn.py:368
+        if (rs) r.prev_dist_nearest = d0;
+    }
+    if (rs) {
+        store_sensor<G>(p, idx, s, draw_layout);
+        if (gl == 0) p.rec[env] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// step kernel: the hot path
+// ---------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(kBlockThreads) void uav_step_kernel(Consts c, Ptrs p, StepArgs a) {
+    extern __shared__ float lds[];
+    const int gl = group_lane<G>();
+    const size_t env = (size_t)blockIdx.x * (kBlockThreads / G) + threadIdx.x / G;
+    const size_t idx = env * G + gl;
+    float* lds_row = lds + (threadIdx.x / G) * c.obs_dim;
+    const bool in_batch = env < (size_t)a.num_envs;
+
+    UavEnvRecord r = p.rec[env];
+    Sensor s;
+    load_sensor<G>(p, idx, s);
+    const int n = r.num_sensors;
+    const bool act = gl < n;
+
+    // ---- action -----------------------------------------------------------------------------
+    const uint32_t step = (uint32_t)(r.current_step + 1);
+    int action;
+    if (a.actions != nullptr) action = in_batch ? a.actions[env] : 0;
+    else {                                                       // uniform-random policy (Philox call 3)
+        Words4 w = noise_words(c.seed, r.env_index, r.episode, step, 0u, 3);
+        action = (int)(((uint64_t)w.w0 * 5u) >> 32);
+        if (a.actions_out != nullptr && in_batch && gl == 0) a.actions_out[env] = action;
+    }
+    const bool is_c = action == 4;
+    const bool is_m = action >= 0 && action <= 3;
+    if (!is_c && !is_m) r.status |= 1u;                         // uav_env.py:468 ValueError (after ageing)
+
+    // ---- uav_env.py:439-447: step counter, edge-cell bookkeeping on the PRE-move position --------
+    r.current_step += 1;
+    {
+        double W = (double)r.grid_w, H = (double)r.grid_h, ux = (double)r.uav_x, uy = (double)r.uav_y;
+        const double eps = 1e-6;
+        if (ux <= eps || uy <= eps || ux >= W - 1 - eps || uy >= H - 1 - eps) r.edge_steps += 1;
+    }
+    // ---- :450-459 age all sensors (iot_sensors.py:114-125), data-loss delta ------------------------
+    const double step_duration = is_c ? c.coll_dur : 1.0;
+    double loss = 0.0;
+    if (act) {
+        double new_data = c.rate * step_duration;
+        s.gen += new_data;
+        double potential = s.b + new_data;
+        if (potential > c.bmax) { loss = potential - c.bmax; s.b = c.bmax; s.lost += loss; }
+        else s.b = potential;
+    }
+    const double step_data_loss = gsum<G>(loss);
+
+    const double prev_dist = r.prev_dist_nearest;               // dqn.py:417
+    double reward = 0.0;
+
+    // ---- :494-516 move (uav.py:127-185, reward_function.py:69-79); scalar per group ---------------
+    if (is_m) {
+        double battery_before = r.battery;
+        float nx = r.uav_x, ny = r.uav_y;
+        if (action == 0) ny += 1.0f; else if (action == 1) ny -= 1.0f;
+        else if (action == 2) nx -= 1.0f; else nx += 1.0f;
+        bool ok = (0 <= nx && nx < (float)r.grid_w && 0 <= ny && ny < (float)r.grid_h);
+        if (ok) { r.uav_x = nx; r.uav_y = ny; r.battery -= c.e_move; }
+        else { r.battery -= c.e_coll; r.boundary_hits += 1; }
+        double battery_used = battery_before - r.battery;
+        reward = c.p_step;
+        reward += ok ? c.r_move : c.p_boundary;
+        reward += c.p_battery * battery_used;
+        reward += c.p_loss * step_data_loss;
+        r.last_step_bytes = 0.0;
+    }
+
+    // One deterministic path-loss evaluation per sensor and step: a collect step does not move the
+    // UAV, so the five RSSI samples of a step (zA,zB,zC at the pre-action position, zD,zE at the
+    // post-action position) all share it.
+    const double det = rssi_deterministic(c, r.uav_x, r.uav_y, s.sx, s.sy);
+
+    const bool any_c = __any(is_c) != 0;
+    StepNoise z;
+    draw_step_noise<G>(c, p, r, env, in_batch, step, any_c, z);
+
+    // ---- :518-632 collect with Capture-Effect collision handling ---------------------------------
+    if (any_c) {
+        const bool actc = act && is_c;
+        float urg_before = 0.0f;
+        if (actc && c.rate > 0) urg_before = (float)(s.b / c.rate);            // P0 :526 (float32 AoI)
+        if (is_c) r.battery -= c.e_hover;                                      // P1 :529
+        // P2 :535-551
+        const bool has = actc && s.b > 0;
+        double cur = 0.0;
+        if (has) {
+            cur = det + c.sigma * (double)z.zA;
+            adr_update(c, cur, s.avg, s.flags);                                 // :539
+        }
+        const uint32_t sf = s.flags & kSfMask;
+        bool attempt = false;
+        if (has) {
+            double rssi = det + c.sigma * (double)z.zB;                         // :543 get_success_probability
+            double p_link = 0.0;
+            if (!(rssi < c.thr)) p_link = 1.0 / (1.0 + exp(-((rssi - c.noise_floor) - sf_required_snr(sf))));
+            attempt = (p_link * c.p_cycle) > (double)z.u;                      // :549
+        }
+        // P3 :554-572: per SF class, sole attempter wins; else top wins iff > second + 6 dB.
+        // Each attempter scans the (few) other attempters of its group.
+        uint64_t m = gballot<G>(attempt);
+        int others = 0;
+        double omax = -__builtin_inf();
+        bool lower_same = false, beaten = false;
+        while (__any(m != 0ull)) {
+            int j = m ? (__ffsll((long long)m) - 1) : 0;
+            double cj = gshfl<G>(cur, j);
+            uint32_t sfj = gshfl<G>(sf, j);
+            if (m != 0ull && attempt && sfj == sf && j != gl) {
+                others += 1;
+                omax = cj > omax ? cj : omax;
+                if (j < gl) lower_same = true;
+                if (cj > cur || (cj == cur && j < gl)) beaten = true;
+            }
+            m &= (m - 1ull);
+        }
+        const bool contested = attempt && others > 0;
+        const bool winner = attempt && (others == 0 || (!beaten && cur > (omax + c.cap_thr)));
+        const int collision_count = __popcll(gballot<G>(contested)) - __popcll(gballot<G>(contested && !lower_same));
+        const int captures = __popcll(gballot<G>(winner && contested));
+        // P4 :575-594 + iot_sensors.py:127-145 collect_data
+        double bytes = 0.0;
+        bool got = false;
+        if (winner) {
+            double rssi = det + c.sigma * (double)z.zC;
+            bool in_range = !(rssi < c.thr);
+            if (in_range && s.b > 0) {
+                double max_collectible = sf_data_rate(sf) * c.coll_dur;
+                bytes = s.b < max_collectible ? s.b : max_collectible;
+                s.b -= bytes;
+                s.tx += bytes;
+                if (bytes > 0) { s.flags |= kDataCollected; got = true; }
+            }
+        }
+        const double total_bytes = gsum<G>(bytes);
+        const bool any_new = gany<G>(got && !(s.flags & kVisited));
+        if (got) s.flags |= kVisited;
+        const int nw = __popcll(gballot<G>(winner));
+        const bool attempted_empty = gany<G>(actc && s.b <= 0);                 // :596
+        const bool all_collected = !gany<G>(actc && s.b > 0);                   // :604
+        // P5 :599-602 (float32)
+        float diff = 0.0f;
+        if (actc) {
+            float urg_after = c.rate > 0 ? (float)(s.b / c.rate) : 0.0f;
+            float d = urg_before - urg_after;
+            diff = d > 0.0f ? d : 0.0f;
+        }
+        const double urgency_reduced = (double)np_sum_f32<G>(diff, n);
+        // P6 :607-630
+        double mean_urgency = 0.0;
+        {
+            double ui = winner ? calc_urgency(c, s.b, s.gen, s.lost) : 0.0;
+            double su = gsum<G>(ui);
+            if (nw > 0) mean_urgency = su / nw;
+        }
+        // reward_function.py:46-57 variance "starvation" penalty (np.var: two-pass, ddof 0)
+        double starvation = 0.0;
+        {
+            double mx = gmax<G>(actc ? s.b : -__builtin_inf());
+            bool use = n > 1 && mx != 0;
+            double nb = (actc && use) ? s.b / mx : 0.0;
+            double mean = gsum<G>(nb) / n;
+            double dv = (actc && use) ? (nb - mean) * (nb - mean) : 0.0;
+            double var = gsum<G>(dv) / n;
+            if (use) starvation = c.p_starvation * var;
+        }
+        if (is_c) {
+            r.total_data_collected += total_bytes;
+            r.last_step_bytes = total_bytes;
+            r.capture_triggers += captures;
+            r.collisions_total += collision_count;
+            double rw = c.p_step + c.p_hover;                                   // reward_function.py:97
+            if (total_bytes > 0) {
+                rw += c.r_byte * total_bytes * mean_urgency;
+                if (any_new) rw += c.r_new;
+            }
+            if (urgency_reduced > 0) rw += c.r_urg * urgency_reduced;
+            if (attempted_empty && total_bytes == 0) rw += c.p_revisit;
+            rw += c.p_battery * c.used_hover;
+            if (collision_count > 0) rw += c.p_collision * collision_count;
+            if (step_data_loss > 0) rw += c.p_loss * step_data_loss;
+            rw += starvation;
+            if (all_collected) rw += c.r_done;
+            reward = rw;
+        }
+    }
+
+    // ---- :471-487 truncation + terminal penalties (reward_function.py:59-67) -------------------
+    bool truncated = false;
+    if (!(r.battery > c.alive_level)) truncated = true;                          // uav.py:224
+    if (r.current_step >= c.max_steps) truncated = true;
+    const int visited_cnt = __popcll(gballot<G>(act && (s.flags & kVisited)));
+    {
+        bool starved = act && s.gen > 0 && (s.tx / s.gen) < c.cr_thr;
+        int starved_cnt = __popcll(gballot<G>(starved));
+        if (truncated) {
+            int unvisited = n - visited_cnt;
+            if (unvisited > 0) reward += c.p_unvisited * unvisited;
+            reward += c.p_starved * starved_cnt;
+        }
+    }
+    r.total_reward += reward;
+
+    // ---- observation of the stepped state (side effect: ADR EMA) -------------------------------
+    const bool auto_reset = (c.flags & UAVENV_FLAG_AUTO_RESET) != 0;
+    const bool do_reset = truncated && auto_reset;
+    {
+        float* dst = nullptr;
+        if (in_batch) {
+            if (do_reset) dst = a.term_obs ? a.term_obs + env * (size_t)c.obs_dim : nullptr;
+            else dst = a.obs ? a.obs + env * (size_t)c.obs_dim : nullptr;
+        }
+        observe<G>(c, s, r, act, true, det, z.zD, z.zE, dst, lds_row);          // :488
+    }
+
+    // ---- DomainRandEnv.step extras (dqn.py:415-444) ---------------------------------------------
+    if (c.flags & UAVENV_FLAG_PROX_SHAPING) {
+        double curr = dist_nearest_with_data<G>(s, act, r.uav_x, r.uav_y);
+        if (prev_dist > 0) reward += c.prox_eta * (prev_dist - curr);
+        r.prev_dist_nearest = curr;
+    }
+    if (r.first_full_coverage_step < 0 && visited_cnt == n) r.first_full_coverage_step = r.current_step;
+    if (c.flags & UAVENV_FLAG_JAIN_BONUS) reward += c.jain_weight * (jains_index<G>(s, act, nullptr) - 0.5) / n;
+    r.episode_return += reward;
+
+    if (in_batch && gl == 0) {
+        if (a.reward) a.reward[env] = reward;
+        if (a.reward32) a.reward32[env] = (float)reward;
+        if (a.done) a.done[env] = truncated ? 1 : 0;
+    }
+
+    // ---- SB3 VecEnv auto-reset: episode stats, reset, first observation of the new episode -----------
+    bool wrote_pos = false;
+    if (__any(do_reset)) {
+        {   // dqn.py:305-331 last_episode_stats (+ Monitor r/l)
+            double std_rates;
+            double jain = jains_index<G>(s, act, &std_rates);
+            double tg = gsum<G>(act ? s.gen : 0.0), tc = gsum<G>(act ? s.tx : 0.0), tl = gsum<G>(act ? s.lost : 0.0);
+            if (do_reset && gl == 0) {
+                UavEnvEpisodeStats st;
+                st.episode_return = r.episode_return; st.total_reward = r.total_reward;
+                st.total_generated = tg; st.total_collected = tc; st.total_lost = tl;
+                st.battery_remaining = r.battery; st.jains_index = jain; st.fairness_std = std_rates;
+                st.length = r.current_step; st.sensors_visited = visited_cnt; st.num_sensors = n;
+                st.grid_w = r.grid_w; st.grid_h = r.grid_h;
+                st.first_full_coverage_step = r.first_full_coverage_step;
+                st.episode = r.episode; st.valid = 1u;
+                p.stats[env] = st;
+            }
+        }
+        float zD = 0.f, zE = 0.f;
+        const bool draw_layout = (c.flags & UAVENV_FLAG_RANDOM_LAYOUT) != 0;
+        reset_group<G>(c, p, s, r, env, in_batch, do_reset, draw_layout, zD, zE);
+        if (c.flags & UAVENV_FLAG_FAR_START) far_start<G>(c, s, r, act, do_reset);
+        if (do_reset) { r.uav_x = r.start_x; r.uav_y = r.start_y; }
+        double det0 = rssi_deterministic(c, r.uav_x, r.uav_y, s.sx, s.sy);
+        float* dst = (in_batch && a.obs) ? a.obs + env * (size_t)c.obs_dim : nullptr;
+        observe<G>(c, s, r, act, do_reset, det0, zD, zE, dst, lds_row);
+        if (c.flags & UAVENV_FLAG_PROX_SHAPING) {
+            double d0 = dist_nearest_with_data<G>(s, act, r.uav_x, r.uav_y);
+            if (do_reset) r.prev_dist_nearest = d0;
+        }
+        wrote_pos = draw_layout && do_reset;
+    }
+
+    store_sensor<G>(p, idx, s, wrote_pos);
+    if (gl == 0) {
+        p.rec[env] = r;
+        if (r.status) atomicOr(p.status, r.status);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// noise dump: the tapes the NEXT step / NEXT reset would draw (parity harness for Philox mode)
+// ---------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(kBlockThreads) void uav_dump_noise_kernel(Consts c, Ptrs p, float* step_tape,
+                                                                       float* reset_tape, int32_t num_envs) {
+    const int gl = group_lane<G>();
+    const size_t env = (size_t)blockIdx.x * (kBlockThreads / G) + threadIdx.x / G;
+    if (env >= (size_t)num_envs) return;
+    UavEnvRecord r = p.rec[env];
+    if (step_tape) {
+        Ptrs q = p; q.step_tape = nullptr;
+        StepNoise z;
+        draw_step_noise<G>(c, q, r, env, true, (uint32_t)(r.current_step + 1), true, z);
+        float* t = step_tape + env * (size_t)(UAVENV_TAPE_STEP_SLOTS * G) + gl;
+        t[0 * G] = z.zA; t[1 * G] = z.zB; t[2 * G] = z.u; t[3 * G] = z.zC; t[4 * G] = z.zD; t[5 * G] = z.zE;
+    }
+    if (reset_tape) {
+        uint32_t ep = r.episode + 1u;
+        Words4 w = noise_words(c.seed, r.env_index, ep, 0u, (uint32_t)gl, 2);
+        Words4 v = noise_words(c.seed, r.env_index, ep, 0u, (uint32_t)gl, 0);
+        float zD, zE;
+        normal_pair(v.w0, v.w1, zD, zE);
+        float* t = reset_tape + env * (size_t)(UAVENV_RTAPE_SLOTS * G) + gl;
+        t[0 * G] = u24(w.w0); t[1 * G] = zD; t[2 * G] = zE;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static inline size_t lds_bytes(int G, const Consts& c) { return (size_t)(kBlockThreads / G) * (size_t)c.obs_dim * sizeof(float); }
+
+#define UAV_DISPATCH_G(G_, CALL)          \
+    switch (G_) {                         \
+        case 16: { constexpr int G = 16; CALL; } break; \
+        case 32: { constexpr int G = 32; CALL; } break; \
+        case 64: { constexpr int G = 64; CALL; } break; \
+        default: return hipErrorInvalidValue;           \
+    }
+
+hipError_t launch_init(int Gw, int padded_envs, const Consts& c, const Ptrs& p, uint32_t env_index_base,
+                       int32_t grid_w, int32_t grid_h, int32_t n, float start_x, float start_y, hipStream_t s) {
+    dim3 block(kBlockThreads), grid((unsigned)(padded_envs / (kBlockThreads / Gw)));
+    UAV_DISPATCH_G(Gw, (uav_init_kernel<G><<<grid, block, 0, s>>>(c, p, env_index_base, grid_w, grid_h, n, start_x, start_y)));
+    return hipGetLastError();
+}
+hipError_t launch_reset(int Gw, int padded_envs, const Consts& c, const Ptrs& p, const ResetArgs& a, hipStream_t s) {
+    dim3 block(kBlockThreads), grid((unsigned)(padded_envs / (kBlockThreads / Gw)));
+    UAV_DISPATCH_G(Gw, (uav_reset_kernel<G><<<grid, block, lds_bytes(Gw, c), s>>>(c, p, a)));
+    return hipGetLastError();
+}
+hipError_t launch_step(int Gw, int padded_envs, const Consts& c, const Ptrs& p, const StepArgs& a, hipStream_t s) {
+    dim3 block(kBlockThreads), grid((unsigned)(padded_envs / (kBlockThreads / Gw)));
+    UAV_DISPATCH_G(Gw, (uav_step_kernel<G><<<grid, block, lds_bytes(Gw, c), s>>>(c, p, a)));
+    return hipGetLastError();
+}
+hipError_t launch_dump_noise(int Gw, int padded_envs, const Consts& c, const Ptrs& p, float* step_tape,
+                             float* reset_tape, int32_t num_envs, hipStream_t s) {
+    dim3 block(kBlockThreads), grid((unsigned)(padded_envs / (kBlockThreads / Gw)));
+    UAV_DISPATCH_G(Gw, (uav_dump_noise_kernel<G><<<grid, block, 0, s>>>(c, p, step_tape, reset_tape, num_envs)));
+    return hipGetLastError();
+}
+
+}  // namespace uavenv

@@ -1,0 +1,134 @@
+// uavenv_noise.h -- counter-based noise for the batched UAV-IoT environment (device + host).
+//
+// Replaces the reference's three process-global RNG streams (np.random.normal at
+// iot_sensors.py:192, stdlib random.random() at uav_env.py:549, gymnasium np_random.uniform at
+// uav_env.py:410) by Philox4x32-10 keyed by the 64-bit seed and addressed by
+//     counter = (global env index, episode, step, lane | call << 16).
+//
+//   call 0 (every step; step 0 = the observation built inside reset):
+//            w0,w1 -> (zD, zE) observation ADR sample / in-range sample;  w2 -> lottery uniform u
+//   call 1 (collect steps only): w0,w1 -> (zA, zB);  w2,w3 -> (zC, unused)
+//   call 2 (reset, step 0):      w0 -> buffer-fill uniform; w1,w2 -> sensor layout x,y;
+//                                lane 0's w3 -> curriculum grid choice
+//   call 3 (lane 0):             w0 -> uniform-random policy action
+//   call 4 (lane field = try):   w0,w1 -> far-start candidate
+//
+// Normals come from a Box-Muller transform written WITHOUT transcendental instructions: only IEEE
+// float32 +,-,*,sqrt and integer ops in a fixed order, compiled with -ffp-contract=off, so the
+// device and any IEEE host produce bit-identical values (the CPU oracle restates the same
+// specification independently in oracle/uavenv_oracle.c).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define UAV_HD __host__ __device__ __forceinline__
+#else
+#define UAV_HD inline
+#endif
+
+namespace uavenv {
+
+struct Words4 { uint32_t w0, w1, w2, w3; };
+
+UAV_HD uint32_t mulhi32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
+#endif
+}
+
+UAV_HD Words4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+        uint32_t hi0 = mulhi32(M0, c0), lo0 = M0 * c0;
+        uint32_t hi1 = mulhi32(M1, c2), lo1 = M1 * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return Words4{c0, c1, c2, c3};
+}
+
+UAV_HD Words4 noise_words(uint64_t seed, uint32_t env, uint32_t episode, uint32_t step, uint32_t lane, uint32_t call) {
+    return philox4x32_10(env, episode, step, lane | (call << 16), (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+UAV_HD float u24(uint32_t w) { return (float)(w >> 8) * 0x1p-24f; }      // [0,1), 24 bits, exact
+
+UAV_HD float bits_to_float(uint32_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    union { uint32_t u; float f; } x; x.u = u; return x.f;
+#endif
+}
+UAV_HD uint32_t float_to_bits(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float_as_uint(f);
+#else
+    union { uint32_t u; float f; } x; x.f = f; return x.u;
+#endif
+}
+UAV_HD float sqrt_rn(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fsqrt_rn(x);
+#else
+    return __builtin_sqrtf(x);
+#endif
+}
+
+// Two standard normals from two 32-bit words.
+//   radius: u1 = ((a>>8)+1) * 2^-24 in (0,1];  -ln u1 by exponent split + degree-9 minimax polynomial
+//           on the mantissa folded into [sqrt(1/2), sqrt(2));
+//   angle:  top 2 bits of (b>>8) choose the quadrant, the low 22 bits the angle in [-pi/4, pi/4);
+//           sin/cos by degree-7/8 minimax polynomials.
+UAV_HD void normal_pair(uint32_t a, uint32_t b, float& z0, float& z1) {
+    uint32_t k = (a >> 8) + 1u;
+    float u1 = (float)k * 0x1p-24f;
+    uint32_t bits = float_to_bits(u1);
+    int ex = (int)(bits >> 23) - 127;
+    float m = bits_to_float((bits & 0x007FFFFFu) | 0x3F800000u);
+    if (m > 1.41421354f) { m = m * 0.5f; ex += 1; }
+    float t = m - 1.0f;
+    float z = t * t;
+    float p = 7.0376836292E-2f;
+    p = p * t + -1.1514610310E-1f;
+    p = p * t + 1.1676998740E-1f;
+    p = p * t + -1.2420140846E-1f;
+    p = p * t + 1.4249322787E-1f;
+    p = p * t + -1.6668057665E-1f;
+    p = p * t + 2.0000714765E-1f;
+    p = p * t + -2.4999993993E-1f;
+    p = p * t + 3.3333331174E-1f;
+    float y = (t * z) * p;
+    y = y + -0.5f * z;
+    float ln = (t + y) + (float)ex * 0.693147182f;
+    float r2 = -2.0f * ln;
+    if (!(r2 > 0.0f)) r2 = 0.0f;
+    float r = sqrt_rn(r2);
+
+    uint32_t kb = b >> 8;
+    uint32_t q = kb >> 22;
+    float f = (float)(kb & 0x003FFFFFu) * 0x1p-22f;
+    float phi = (f - 0.5f) * 1.57079637f;
+    float zz = phi * phi;
+    float s = -1.9515295891E-4f;
+    s = s * zz + 8.3321608736E-3f;
+    s = s * zz + -1.6666654611E-1f;
+    s = (s * zz) * phi + phi;
+    float c = 2.443315711809948E-5f;
+    c = c * zz + -1.388731625493765E-3f;
+    c = c * zz + 4.166664568298827E-2f;
+    c = (c * zz) * zz + (1.0f - 0.5f * zz);
+    float cs = (q & 1u) ? s : c;
+    float sn = (q & 1u) ? c : s;
+    if (q == 1u || q == 2u) cs = -cs;
+    if (q >= 2u) sn = -sn;
+    z0 = r * cs;
+    z1 = r * sn;
+}
+
+}  // namespace uavenv

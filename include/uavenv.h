@@ -1,0 +1,215 @@
+/*
+ * uavenv.h -- C ABI of the MI355X-native batched UAV-IoT environment (libuavenv_hip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of the reference: the Gymnasium environment
+ * reset()/step() chain of
+ *     /root/reference/src/environment/uav_env.py      (UAVEnvironment, :240)
+ *     /root/reference/src/environment/iot_sensors.py  (IoTSensor, :10)
+ *     /root/reference/src/environment/uav.py          (UAV, :63)
+ *     /root/reference/src/rewards/reward_function.py  (RewardFunction, :4)
+ * batched over E independent environment instances and executed by hand-written HIP kernels for
+ * gfx950 (one 16/32/64-lane group of a wavefront per environment, one lane per sensor).
+ *
+ * Conventions
+ *   - plain C: opaque handle, plain pointers and sizes, no C++/torch types;
+ *   - every function returns 0 on success or a negative UAVENV_E_* code and never throws or aborts;
+ *     uavenv_last_error() gives the text;
+ *   - `*_dev` pointers are device (HBM) pointers valid on the handle's device; `stream` is a
+ *     hipStream_t passed as void* (NULL = the null stream); calls are asynchronous on that stream
+ *     unless stated otherwise;
+ *   - per-sensor arrays are laid out [num_envs][lane_stride] where lane_stride =
+ *     uavenv_lane_stride() (16, 32 or 64: the lane-group width that holds max_sensors).
+ *
+ * The reference interface each entry point replaces is cited next to it.
+ */
+#ifndef UAVENV_H
+#define UAVENV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UAVENV_ABI_VERSION 1
+
+/* error codes */
+#define UAVENV_OK              0
+#define UAVENV_E_INVALID      -1   /* bad argument / config                                   */
+#define UAVENV_E_HIP          -2   /* a HIP runtime call failed                               */
+#define UAVENV_E_ACTION       -3   /* an action outside 0..4 was seen (uav_env.py:468)        */
+#define UAVENV_E_ALLOC        -4
+
+/* UavEnvConfig.flags */
+#define UAVENV_FLAG_RANDOM_LAYOUT  1u   /* dqn.py:342-360 fresh uniform layout + empty buffers per reset */
+#define UAVENV_FLAG_FAR_START      2u   /* dqn.py:364-365,375-403 rejection-sampled UAV start            */
+#define UAVENV_FLAG_PROX_SHAPING   4u   /* dqn.py:417-425 proximity shaping reward                       */
+#define UAVENV_FLAG_JAIN_BONUS     8u   /* dqn.py:434-442 per-step Jain's fairness bonus                 */
+#define UAVENV_FLAG_AUTO_RESET    16u   /* SB3 VecEnv semantics: reset inside step() on truncation        */
+
+/* Every constant of the path is a runtime parameter.  Defaults (uavenv_default_config)
+ * are the reference's training configuration: BASE_ENV_CONFIG (agents/dqn/dqn.py:1068-1075) over the
+ * UAVEnvironment kwargs (uav_env.py:266-287), IoTSensor (iot_sensors.py:39-57), UAV (uav.py:93-94,125)
+ * and RewardFunction (reward_function.py:7-27 as overridden at uav_env.py:339-344). */
+typedef struct UavEnvConfig {
+    uint32_t struct_size;              /* = sizeof(UavEnvConfig); checked by uavenv_create           */
+    int32_t  grid_w, grid_h;           /* uav_env.py:268 grid_size                                    */
+    int32_t  num_sensors;              /* uav_env.py:270 (<= 64)                                      */
+    int32_t  max_steps;                /* uav_env.py:280                                              */
+    int32_t  include_sensor_positions; /* uav_env.py:286 -> 5 features per sensor instead of 3        */
+    int32_t  pad_sensors;              /* dqn.py:286-298: zero-pad the observation to this many slots */
+    uint32_t flags;                    /* UAVENV_FLAG_*                                               */
+    int32_t  max_start_tries;          /* dqn.py NAV_CONFIG["max_start_tries"]                        */
+    int32_t  use_ema_adr;              /* iot_sensors.py:54                                           */
+    int32_t  num_grid_choices;         /* dqn.py:280-283 curriculum grid list; 0 = keep grid_w/grid_h */
+    int32_t  grid_choices_w[8], grid_choices_h[8];
+    uint64_t seed;                     /* Philox key: replaces the reference's three global RNG streams */
+    double data_generation_rate, max_buffer_size, rssi_threshold, duty_cycle;      /* uav_env.py:271-276 */
+    double start_x, start_y, max_battery, collection_duration;                     /* uav_env.py:277-279 */
+    double tx_power_dbm, noise_floor_dbm, uav_altitude, sensor_height, wavelength, freq_mhz,
+           fspl_offset_db, adr_lambda, shadowing_std_db, capture_threshold_db;     /* iot_sensors.py:39-57,147-197; uav_env.py:567 */
+    double sf_thresholds[4];           /* iot_sensors.py:32-37 -> SF 7, 9, 11, 12                      */
+    double fill_lo, fill_hi;           /* uav_env.py:410 initial buffer fill U(lo, hi)                 */
+    double power_move, power_hover, alive_fraction;                                /* uav.py:93-94, :224 */
+    double reward_per_byte, reward_new_sensor, reward_completion, reward_urgency_reduction,
+           reward_movement, penalty_revisit, penalty_boundary, penalty_collision, penalty_battery,
+           penalty_hover, penalty_step, penalty_data_loss, penalty_starvation, penalty_unvisited,
+           penalty_starved, starvation_cr_threshold;                               /* reward_function.py:7-27 */
+    double min_start_dist, prox_eta, jain_weight;                                  /* dqn.py NAV_CONFIG, :442 */
+} UavEnvConfig;
+
+/* Per-environment scalar state as stored in HBM (128 bytes, one record per environment).
+ * Mirrors the attributes callers of the reference reach into: env.uav.position / .battery,
+ * env.current_step, env.total_reward, env.total_data_collected, env.capture_effect_triggers,
+ * env.boundary_hits, env.edge_steps (uav_env.py:293-303, 676-700). */
+typedef struct UavEnvRecord {
+    double  battery;               /* uav.py:120 (Wh)                                     */
+    double  total_reward;          /* uav_env.py:487 (unshaped)                           */
+    double  total_data_collected;  /* uav_env.py:588                                      */
+    double  last_step_bytes;       /* uav_env.py:607                                      */
+    double  prev_dist_nearest;     /* dqn.py:368, :425                                    */
+    double  episode_return;        /* sum of RETURNED (shaped) rewards: Monitor's info["episode"]["r"] */
+    float   uav_x, uav_y;          /* uav.py:113 (float32 grid units)                     */
+    float   start_x, start_y;      /* uav.py:112                                          */
+    int32_t current_step;          /* uav_env.py:439                                      */
+    uint32_t episode;              /* number of resets - 1 (Philox counter word 1)        */
+    int32_t capture_triggers, boundary_hits, edge_steps, collisions_total;
+    int32_t first_full_coverage_step;   /* dqn.py:428-431; -1 = not yet                   */
+    int32_t grid_w, grid_h, num_sensors;
+    uint32_t env_index;            /* GLOBAL environment index (Philox counter word 0)    */
+    uint32_t status;               /* bit 0: an invalid action was seen                   */
+    uint32_t reserved[4];
+} UavEnvRecord;
+
+/* Written once per finished episode when UAVENV_FLAG_AUTO_RESET is set (what DomainRandEnv.reset
+ * snapshots into last_episode_stats, dqn.py:305-331, plus Monitor's r/l). */
+typedef struct UavEnvEpisodeStats {
+    double  episode_return, total_reward, total_generated, total_collected, total_lost,
+            battery_remaining, jains_index, fairness_std;
+    int32_t length, sensors_visited, num_sensors, grid_w, grid_h, first_full_coverage_step;
+    uint32_t episode, valid;
+} UavEnvEpisodeStats;
+
+/* fields for uavenv_get_state / uavenv_set_state */
+enum {
+    UAVENV_F_POS_X = 0,    /* float  [E][stride]  iot_sensors.py:66 position[0]          */
+    UAVENV_F_POS_Y = 1,    /* float  [E][stride]                                        */
+    UAVENV_F_BUFFER = 2,   /* double [E][stride]  data_buffer                           */
+    UAVENV_F_GEN = 3,      /* double [E][stride]  total_data_generated                  */
+    UAVENV_F_TX = 4,       /* double [E][stride]  total_data_transmitted                */
+    UAVENV_F_LOST = 5,     /* double [E][stride]  total_data_lost                       */
+    UAVENV_F_AVG_RSSI = 6, /* double [E][stride]  avg_rssi (valid iff flag bit 4)       */
+    UAVENV_F_FLAGS = 7,    /* uint32 [E][stride]  bits 0-3 SF, 4 avg_valid, 5 visited, 6 data_collected */
+    UAVENV_F_RECORD = 8,   /* UavEnvRecord [E]                                          */
+    UAVENV_F_EPISODE_STATS = 9, /* UavEnvEpisodeStats [E]                              */
+    UAVENV_F_COUNT = 10
+};
+
+/* noise-tape slots (float [E][slots][stride]); NULL tape = in-kernel Philox4x32-10 */
+enum { UAVENV_TAPE_ZA = 0, UAVENV_TAPE_ZB, UAVENV_TAPE_U, UAVENV_TAPE_ZC, UAVENV_TAPE_ZD, UAVENV_TAPE_ZE,
+       UAVENV_TAPE_STEP_SLOTS };
+enum { UAVENV_RTAPE_FILL = 0, UAVENV_RTAPE_ZD, UAVENV_RTAPE_ZE, UAVENV_RTAPE_SLOTS };
+
+typedef struct UavEnv UavEnv;
+
+/* ---- configuration ------------------------------------------------------------------------- */
+int uavenv_abi_version(void);
+/* replaces: the defaults of UAVEnvironment.__init__ (uav_env.py:266-287) + BASE_ENV_CONFIG (dqn.py:1068-1075) */
+int uavenv_default_config(UavEnvConfig* cfg);
+/* replaces: observation_space.shape[0] (uav_env.py:348-355; padded form dqn.py:249-254) */
+int uavenv_obs_dim(const UavEnvConfig* cfg);
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+/* replaces: UAVEnvironment.__init__ (uav_env.py:266-361) for `num_envs` instances.  env_index_base is
+ * the GLOBAL index of this shard's first environment (multi-GPU: rank r owns [base, base+num_envs)), so
+ * results do not depend on how environments are sharded.  Sensor layouts are drawn per environment from
+ * the Philox key (replaces _generate_uniform_sensor_positions, uav_env.py:366-374). */
+int uavenv_create(const UavEnvConfig* cfg, int32_t num_envs, uint32_t env_index_base, int32_t device, UavEnv** out);
+int uavenv_destroy(UavEnv* env);                       /* replaces: close() (uav_env.py:893-895) */
+const char* uavenv_last_error(const UavEnv* env);      /* env may be NULL: error of a failed create */
+
+int uavenv_num_envs(const UavEnv* env);
+int uavenv_lane_stride(const UavEnv* env);
+int uavenv_env_obs_dim(const UavEnv* env);
+
+/* ---- per-environment parameters (BASELINE config 5: mixed grid / sensor-count sweeps) ------- */
+/* host arrays of num_envs entries, each nullable; takes effect at the next reset of each env */
+int uavenv_set_env_params(UavEnv* env, const int32_t* grid_w, const int32_t* grid_h, const int32_t* num_sensors);
+/* replaces: the sensor_positions kwarg (uav_env.py:269); host float [E][stride] */
+int uavenv_set_positions(UavEnv* env, const float* pos_x, const float* pos_y);
+/* replaces: reset(seed=...) / VecEnv.seed(): re-keys all randomness */
+int uavenv_set_seed(UavEnv* env, uint64_t seed);
+/* replaces: DomainRandEnv.set_curriculum_stage (dqn.py:258-277): grid list sampled at each reset */
+int uavenv_set_grid_choices(UavEnv* env, int32_t count, const int32_t* w, const int32_t* h);
+
+/* ---- noise tape (parity testing) ------------------------------------------------------------ */
+/* step_tape_dev: float [E][6][stride] consumed by the next uavenv_step; reset_tape_dev:
+ * float [E][3][stride] consumed by uavenv_reset and by auto-resets.  NULL restores Philox. */
+int uavenv_set_noise_tape(UavEnv* env, const float* step_tape_dev, const float* reset_tape_dev);
+/* writes the tapes the NEXT step (and a reset opening the next episode) would draw from Philox */
+int uavenv_dump_noise(UavEnv* env, float* step_tape_out_dev, float* reset_tape_out_dev, void* stream);
+
+/* ---- the hot path --------------------------------------------------------------------------- */
+/* replaces: UAVEnvironment.reset (uav_env.py:400-427; DomainRandEnv.reset dqn.py:301-373 under the
+ * RANDOM_LAYOUT / FAR_START flags).  mask_dev: uint8 [E], nullable = reset all.
+ * obs_out_dev: float [E][obs_dim], rows of unmasked envs are left untouched. */
+int uavenv_reset(UavEnv* env, const uint8_t* mask_dev, float* obs_out_dev, void* stream);
+
+/* replaces: UAVEnvironment.step (uav_env.py:429-488; DomainRandEnv.step dqn.py:415-444 under the
+ * shaping flags), for all E environments in ONE kernel launch.
+ *   actions_dev       int32 [E]           0 UP(+y) 1 DOWN(-y) 2 LEFT(-x) 3 RIGHT(+x) 4 COLLECT (uav_env.py:497)
+ *   obs_out_dev       float [E][obs_dim]  observation after the step (after the auto-reset when one happened)
+ *   reward_out_dev    double [E]          nullable
+ *   reward32_out_dev  float [E]           nullable (what SB3's VecEnv hands the agent)
+ *   done_out_dev      uint8 [E]           truncated flag (`terminated` is always False: uav_env.py:471)
+ *   terminal_obs_dev  float [E][obs_dim]  nullable; rows written only where done (SB3 "terminal_observation") */
+int uavenv_step(UavEnv* env, const int32_t* actions_dev, float* obs_out_dev, double* reward_out_dev,
+                float* reward32_out_dev, uint8_t* done_out_dev, float* terminal_obs_dev, void* stream);
+
+/* same, with the uniform-random policy of BASELINE.md section 4 drawn in-kernel (Philox call 3);
+ * actions_out_dev (int32 [E], nullable) receives the actions taken. */
+int uavenv_step_random(UavEnv* env, int32_t* actions_out_dev, float* obs_out_dev, double* reward_out_dev,
+                       float* reward32_out_dev, uint8_t* done_out_dev, float* terminal_obs_dev, void* stream);
+
+/* ---- state access (checkpoint / parity / the attribute reads of SURVEY 1) -------------------- */
+/* Copies one whole field.  `bytes` must equal the field size; dst/src may be host or device. */
+int uavenv_get_state(UavEnv* env, int32_t field, void* dst, size_t bytes, int32_t dst_on_device, void* stream);
+int uavenv_set_state(UavEnv* env, int32_t field, const void* src, size_t bytes, int32_t src_on_device, void* stream);
+size_t uavenv_state_bytes(const UavEnv* env, int32_t field);
+
+/* ---- synchronous host-buffer convenience (the reference hands numpy arrays across the boundary) -- */
+int uavenv_reset_host(UavEnv* env, const uint8_t* mask, float* obs_out);
+int uavenv_step_host(UavEnv* env, const int32_t* actions, float* obs_out, double* reward_out,
+                     uint8_t* done_out, float* terminal_obs_out);
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+/* Runs `steps` uavenv_step_random launches back to back on `stream`, bracketed by HIP events on that
+ * same stream; returns the average milliseconds per launch (bench.py's roofline.achieved comes from it). */
+int uavenv_time_steps(UavEnv* env, int32_t steps, float* obs_out_dev, double* reward_out_dev,
+                      uint8_t* done_out_dev, void* stream, float* avg_ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UAVENV_H */

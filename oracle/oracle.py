@@ -99,6 +99,9 @@ def lib():
         L.orc_normal_pair.argtypes = [C.c_uint32, C.c_uint32, fp, fp]
         L.orc_run_random_policy.argtypes = [C.POINTER(OrcConfig), C.c_int, C.c_uint32, C.c_int, C.POINTER(_D)]
         L.orc_run_random_policy.restype = C.c_long
+        L.orc_trace_keyed.argtypes = [C.POINTER(OrcConfig), C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_trace_keyed.restype = C.c_long
         L.orc_rssi_deterministic.argtypes = [C.POINTER(OrcConfig), C.c_float, C.c_float, C.c_float, C.c_float]
         L.orc_rssi_deterministic.restype = _D
         assert C.sizeof(OrcConfig) > 0
@@ -217,3 +220,41 @@ def run_random_policy(cfg, num_envs, steps, env_index_base=0):
     s = _D()
     n = lib().orc_run_random_policy(C.byref(cfg), num_envs, env_index_base, steps, C.byref(s))
     return n, s.value
+
+
+def _env_state(e, n):
+    arr = lambda f, dt: np.ctypeslib.as_array(getattr(e, f))[:n].astype(dt)
+    avg = arr("avg_rssi", np.float64)
+    avg[arr("avg_valid", np.uint8) == 0] = np.nan
+    return dict(buffer=arr("buffer", np.float64), gen=arr("gen", np.float64), tx=arr("tx", np.float64),
+                lost=arr("lost", np.float64), avg_rssi=avg, sf=arr("sf", np.int32),
+                visited=arr("visited", np.uint8), data_collected=arr("data_collected", np.uint8),
+                pos_x=arr("pos_x", np.float32), pos_y=arr("pos_y", np.float32),
+                uav_x=np.float32(e.uav_x), uav_y=np.float32(e.uav_y), battery=np.float64(e.battery),
+                step=np.int32(e.current_step), total_reward=np.float64(e.total_reward),
+                total_collected=np.float64(e.total_data_collected), episode=np.uint32(e.episode),
+                capture_triggers=np.int32(e.capture_triggers), boundary_hits=np.int32(e.boundary_hits),
+                edge_steps=np.int32(e.edge_steps), collisions_total=np.int32(e.collisions_total),
+                grid_w=np.int32(e.grid_w), grid_h=np.int32(e.grid_h),
+                start_x=np.float32(e.start_x), start_y=np.float32(e.start_y))
+
+
+def trace_keyed(cfg, num_envs, steps, base=0, actions=None, auto_reset=True):
+    """Run the keyed oracle for a batch; returns dict(obs[steps,E,D], reward, done, term_obs, actions,
+    reset_obs[E,D], final=[per-env state dicts])."""
+    L = lib()
+    D = L.orc_obs_dim(C.byref(cfg), cfg.num_sensors)
+    E = num_envs
+    obs = np.zeros((steps, E, D), np.float32); term = np.zeros((steps, E, D), np.float32)
+    rew = np.zeros((steps, E), np.float64); done = np.zeros((steps, E), np.uint8)
+    acts_out = np.zeros((steps, E), np.int32); reset_obs = np.zeros((E, D), np.float32)
+    finals = (OrcEnv * E)()
+    ap = None
+    if actions is not None:
+        actions = np.ascontiguousarray(actions, np.int32); assert actions.shape == (steps, E)
+        ap = actions.ctypes.data_as(C.c_void_p)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    L.orc_trace_keyed(C.byref(cfg), E, base, steps, ap, int(auto_reset), vp(obs), vp(rew), vp(done), vp(term),
+                      vp(acts_out), vp(reset_obs), C.cast(finals, C.c_void_p))
+    return dict(obs=obs, reward=rew, done=done, term_obs=term, actions=acts_out, reset_obs=reset_obs,
+                final=[_env_state(finals[i], cfg.num_sensors) for i in range(E)])

@@ -104,8 +104,8 @@ double orc_rssi_deterministic(const OrcConfig* c, float ux, float uy, float sx, 
     float dx = (ux - sx) * 10.0f;                         /* :161 */
     float dy = (uy - sy) * 10.0f;                         /* :162 */
     float ground = sqrtf(dx * dx + dy * dy);              /* :163 */
-    float alt = (float)c->uav_altitude;
-    float d = sqrtf(ground * ground + alt * alt);         /* :164  (altitude**2 is an int -> float32) */
+    float alt2 = (float)(c->uav_altitude * c->uav_altitude);   /* altitude**2 is a Python scalar -> weak float32 */
+    float d = sqrtf(ground * ground + alt2);              /* :164 */
     double ht = c->sensor_height, hr = c->uav_altitude;
     double d_break = (4 * M_PI * ht * hr) / c->wavelength;    /* :174 */
     float l10 = (float)log10((double)d);                  /* correctly rounded float32 log10 */
@@ -739,5 +739,48 @@ long orc_run_random_policy(const OrcConfig* c, int num_envs, uint32_t env_index_
     }
     free(envs);
     if (reward_checksum) *reward_checksum = sum;
+    return count;
+}
+
+/* Trace runner for the parity tests: `steps` vector steps of `num_envs` keyed environments
+ * (global indices base..base+num_envs-1), actions given ([steps][E]) or drawn by the random policy,
+ * with SB3-style auto-reset when `auto_reset` (the step's own observation goes to term_out, the
+ * reset observation to obs_out).  Any output pointer may be NULL.  final_envs: OrcEnv[num_envs]. */
+long orc_trace_keyed(const OrcConfig* c, int num_envs, uint32_t base, int steps, const int32_t* actions,
+                     int auto_reset, float* obs_out, double* rew_out, uint8_t* done_out, float* term_out,
+                     int32_t* actions_out, float* reset_obs_out, OrcEnv* final_envs) {
+    OrcEnv* envs = (OrcEnv*)malloc(sizeof(OrcEnv) * (size_t)num_envs);
+    int D = orc_obs_dim(c, c->num_sensors);
+    float obs[3 + 5 * ORC_MAX_SENSORS + 5 * 64];
+    float px[ORC_MAX_SENSORS], py[ORC_MAX_SENSORS];
+    long count = 0;
+    for (int k = 0; k < num_envs; k++) {
+        uint32_t idx = base + (uint32_t)k;
+        orc_noise_positions(c->seed, idx, 0xFFFFFFFFu, c->num_sensors, c->grid_w, c->grid_h, px, py);
+        orc_init(&envs[k], c, idx, px, py);
+        orc_reset_keyed(&envs[k], obs);
+        if (reset_obs_out) memcpy(reset_obs_out + (size_t)k * D, obs, sizeof(float) * (size_t)D);
+    }
+    for (int s = 0; s < steps; s++) {
+        for (int k = 0; k < num_envs; k++) {
+            OrcEnv* e = &envs[k];
+            size_t row = (size_t)s * (size_t)num_envs + (size_t)k;
+            int a = actions ? actions[row]
+                            : orc_noise_action(c->seed, e->env_index, e->episode, (uint32_t)(e->current_step + 1));
+            double r = 0.0; int tr = 0;
+            orc_step_keyed(e, a, obs, &r, &tr);
+            count++;
+            if (actions_out) actions_out[row] = a;
+            if (rew_out) rew_out[row] = r;
+            if (done_out) done_out[row] = (uint8_t)tr;
+            if (tr && auto_reset) {
+                if (term_out) memcpy(term_out + row * D, obs, sizeof(float) * (size_t)D);
+                orc_reset_keyed(e, obs);
+            }
+            if (obs_out) memcpy(obs_out + row * D, obs, sizeof(float) * (size_t)D);
+        }
+    }
+    if (final_envs) memcpy(final_envs, envs, sizeof(OrcEnv) * (size_t)num_envs);
+    free(envs);
     return count;
 }

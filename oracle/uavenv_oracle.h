@@ -111,6 +111,10 @@ int  orc_step_keyed(OrcEnv* e, int action, float* obs_out, double* reward_out, i
 long orc_run_random_policy(const OrcConfig* c, int num_envs, uint32_t env_index_base, int steps,
                            double* reward_checksum);
 
+long orc_trace_keyed(const OrcConfig* c, int num_envs, uint32_t base, int steps, const int32_t* actions,
+                     int auto_reset, float* obs_out, double* rew_out, uint8_t* done_out, float* term_out,
+                     int32_t* actions_out, float* reset_obs_out, OrcEnv* final_envs);
+
 /* Scalar known-answer helpers. */
 double orc_rssi_deterministic(const OrcConfig* c, float ux, float uy, float sx, float sy);
 
