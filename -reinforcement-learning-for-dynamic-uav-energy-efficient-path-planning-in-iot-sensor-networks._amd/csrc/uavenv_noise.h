@@ -72,13 +72,10 @@ UAV_HD uint32_t float_to_bits(float f) {
     union { uint32_t u; float f; } x; x.f = f; return x.u;
 #endif
 }
-UAV_HD float sqrt_rn(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __fsqrt_rn(x);
-#else
-    return __builtin_sqrtf(x);
-#endif
-}
+// Correctly rounded float32 square root on both sides.  NOTE: on gfx950 `__fsqrt_rn` lowers to a bare
+// v_sqrt_f32 (1 ulp); `__builtin_sqrtf` gets the fma fix-up sequence and IS correctly rounded (hipcc's
+// default -fhip-fp32-correctly-rounded-divide-sqrt), which numpy's float32 sqrt requires.
+UAV_HD float sqrt_rn(float x) { return __builtin_sqrtf(x); }
 
 // Two standard normals from two 32-bit words.
 //   radius: u1 = ((a>>8)+1) * 2^-24 in (0,1];  -ln u1 by exponent split + degree-9 minimax polynomial
