@@ -163,21 +163,32 @@ class BatchedUAVEnv:
         N.check(self.L.uavenv_reset(self._h, self._p(mask), self._p(self.obs), self._stream()), self._h)
         return self.obs
 
-    def step(self, actions):
+    def _obs_target(self, obs_out):
+        if obs_out is None:
+            return self.obs
+        assert obs_out.is_cuda and obs_out.dtype == torch.float32 and obs_out.is_contiguous()
+        assert tuple(obs_out.shape) == (self.num_envs, self.obs_dim), tuple(obs_out.shape)
+        return obs_out
+
+    def step(self, actions, obs_out=None):
         """uav_env.py:429-488 for all E environments in one launch.
         actions: int32 cuda tensor [E].  Returns (obs, reward float64, done uint8); with auto_reset the
-        rows of `self.terminal_obs` are valid where done."""
+        rows of `self.terminal_obs` are valid where done.  obs_out: optional [E, D] destination (e.g. a
+        slot of a replay ring) written directly by the kernel instead of `self.obs`."""
         assert actions.is_cuda and actions.dtype == torch.int32 and actions.numel() == self.num_envs
-        N.check(self.L.uavenv_step(self._h, self._p(actions), self._p(self.obs), self._p(self.reward),
+        obs = self._obs_target(obs_out)
+        N.check(self.L.uavenv_step(self._h, self._p(actions), self._p(obs), self._p(self.reward),
                                    self._p(self.reward32), self._p(self.done), self._p(self.terminal_obs),
                                    self._stream()), self._h)
-        return self.obs, self.reward, self.done
+        return obs, self.reward, self.done
 
-    def step_random(self):
-        N.check(self.L.uavenv_step_random(self._h, self._p(self.actions_taken), self._p(self.obs), self._p(self.reward),
+    def step_random(self, obs_out=None):
+        """Same with the uniform-random policy drawn in-kernel; the actions land in `self.actions_taken`."""
+        obs = self._obs_target(obs_out)
+        N.check(self.L.uavenv_step_random(self._h, self._p(self.actions_taken), self._p(obs), self._p(self.reward),
                                           self._p(self.reward32), self._p(self.done), self._p(self.terminal_obs),
                                           self._stream()), self._h)
-        return self.obs, self.reward, self.done
+        return obs, self.reward, self.done
 
     def time_steps(self, steps):
         """Average milliseconds per step launch, HIP events on the launch stream (bench.py)."""

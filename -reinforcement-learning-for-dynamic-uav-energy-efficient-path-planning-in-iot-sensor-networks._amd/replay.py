@@ -1,0 +1,94 @@
+"""Shared replay ring fed by an all-gather of transition batches (BASELINE config 4).
+
+One process per GPU owns a shard of environments.  Each vector step produces, per rank, a
+transition block  obs[E_local, D] float32 + aux[E_local, 4] float32 (action, reward, done, pad).
+The step kernel writes its observations DIRECTLY into this rank's slice of the ring slot
+(`slot_obs(slot)[rank]`), so inserting into the replay buffer costs no copy; the other ranks'
+slices arrive through one in-place `all_gather_into_tensor` per tensor (RCCL over xGMI when the
+backend is "nccl"; "gloo" on CPU for the multi-process tests).  The collective is issued on a side
+stream so that it overlaps the next environment step.
+
+next_obs is not stored: it is the following slot's obs, except where `done`, where the
+terminal observation is kept in a small side table (SB3's "terminal_observation" semantics).
+"""
+import torch
+import torch.distributed as dist
+
+
+class TransitionRing:
+    def __init__(self, capacity, envs_per_rank, obs_dim, device, world_size=1, rank=0, group=None):
+        self.capacity, self.E, self.D = int(capacity), int(envs_per_rank), int(obs_dim)
+        self.world, self.rank, self.group = int(world_size), int(rank), group
+        self.device = torch.device(device)
+        # [slot][rank][env][...]: a rank's block is contiguous => in-place all-gather
+        self.obs = torch.zeros(self.capacity, self.world, self.E, self.D, dtype=torch.float32, device=self.device)
+        self.aux = torch.zeros(self.capacity, self.world, self.E, 4, dtype=torch.float32, device=self.device)
+        self.head = 0                 # next slot to write
+        self.size = 0                 # number of valid slots
+        self._pending = [None] * self.capacity
+        self._comm_stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+
+    # ---- producer side -----------------------------------------------------------------------
+    def local_obs_slot(self, slot=None):
+        """[E, D] view of THIS rank's slice of a slot: pass it as `obs_out` to BatchedUAVEnv.step*()."""
+        return self.obs[self.head if slot is None else slot, self.rank]
+
+    def wait_slot(self, slot):
+        w = self._pending[slot]
+        if w is not None:
+            for x in w:
+                x.wait()
+            self._pending[slot] = None
+
+    def commit(self, actions, reward, done):
+        """Record (action, reward, done) of the step whose observations were written into
+        local_obs_slot(), then publish this rank's block of the slot to every rank."""
+        slot = self.head
+        aux = self.aux[slot, self.rank]
+        aux[:, 0] = actions.to(torch.float32)
+        aux[:, 1] = reward.to(torch.float32)
+        aux[:, 2] = done.to(torch.float32)
+        if self.world > 1:
+            if self._comm_stream is not None:
+                self._comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(self._comm_stream):
+                    w1 = dist.all_gather_into_tensor(self.obs[slot].view(-1), self.obs[slot, self.rank].reshape(-1),
+                                                     group=self.group, async_op=True)
+                    w2 = dist.all_gather_into_tensor(self.aux[slot].view(-1), self.aux[slot, self.rank].reshape(-1),
+                                                     group=self.group, async_op=True)
+            else:   # CPU / gloo (tests): same calls, synchronous streams
+                w1 = dist.all_gather_into_tensor(self.obs[slot].view(-1), self.obs[slot, self.rank].reshape(-1).clone(),
+                                                 group=self.group, async_op=True)
+                w2 = dist.all_gather_into_tensor(self.aux[slot].view(-1), self.aux[slot, self.rank].reshape(-1).clone(),
+                                                 group=self.group, async_op=True)
+            self._pending[slot] = (w1, w2)
+        self.head = (slot + 1) % self.capacity
+        self.size = min(self.size + 1, self.capacity)
+        # the slot about to be overwritten next must have finished its previous gather
+        self.wait_slot(self.head)
+        return slot
+
+    def drain(self):
+        for s in range(self.capacity):
+            self.wait_slot(s)
+        if self._comm_stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._comm_stream)
+
+    # ---- consumer side -----------------------------------------------------------------------
+    def sample(self, batch_size, generator=None):
+        """Uniform sample of transitions (obs, action, reward, done, next_obs) over all ranks' envs.
+        Only slots whose successor slot is valid are eligible (next_obs = successor's obs)."""
+        assert self.size >= 2
+        self.drain()
+        n_slots = self.size - 1
+        newest = (self.head - 1) % self.capacity
+        oldest = (self.head - self.size) % self.capacity
+        k = torch.randint(0, n_slots, (batch_size,), generator=generator, device=self.device)
+        slot = (oldest + k) % self.capacity
+        nxt = (slot + 1) % self.capacity
+        r = torch.randint(0, self.world, (batch_size,), generator=generator, device=self.device)
+        e = torch.randint(0, self.E, (batch_size,), generator=generator, device=self.device)
+        aux = self.aux[slot, r, e]
+        assert newest != oldest or self.size == 1
+        return dict(obs=self.obs[slot, r, e], action=aux[:, 0].long(), reward=aux[:, 1], done=aux[:, 2] > 0.5,
+                    next_obs=self.obs[nxt, r, e])

@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the batched UAV-IoT environment step() on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE pass of the hot path over the whole batch: one launch of the HIP step kernel
+(uavenv_step_random: uniform-random policy drawn in-kernel) advancing all
+4096 environments x 50 sensors of this GPU by one env-step each -- ageing, move/collect with
+Capture-Effect resolution, reward, truncation, auto-reset, float32 observation -- with every
+output (obs [E,153], reward, done) written to HBM every step.  State and outputs are resident in
+HBM; nothing crosses PCIe inside the timed region.
+
+Multi-GPU (--gpus N > 1, one process per GPU): weak scaling, every rank owns 4096 environments
+(global indices rank*4096 ..), writes its observations straight into its slice of a shared replay
+ring and publishes the transition block to all ranks with an RCCL all-gather per step, issued on a
+side stream so it overlaps the next step (BASELINE config 4).  `value` = env-steps of ALL ranks /
+max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import glob
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_env_step(n, padded_to=None):
+    """B(N) = 68*N + 104 (+ 12*(pad-N) if padded)."""
+    b = 68 * n + 104
+    if padded_to and padded_to > n:
+        b += 12 * (padded_to - n)
+    return b
+
+
+def cpu_baseline(num_sensors, grid, seconds_target=12.0):
+    """The CPU oracle (a C restatement of the reference, kind "port") timed on ONE host core over a
+    bounded sample of the same workload: the first 256 of the 4096 environments, random policy,
+    auto-reset, for as many vector steps as fit the time target."""
+    from oracle import oracle as O
+    cfg = O.default_config(num_sensors=num_sensors, grid_size=grid, seed=0)
+    envs = 256
+    t0 = time.perf_counter()
+    n, _ = O.run_random_policy(cfg, envs, 40)            # calibrate
+    rate = n / (time.perf_counter() - t0)
+    steps = max(50, int(seconds_target * rate / envs))
+    t0 = time.perf_counter()
+    n, _ = O.run_random_policy(cfg, envs, steps)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"first {envs} of the 4096 envs x {num_sensors} sensors, {steps} vector steps "
+                      f"({n} env-steps, {dt:.1f} s), oracle/uavenv_oracle.c, 1 thread",
+            "reference_python_1core_survey": {"n20": 1692, "n50": 764, "unit": "env-steps/s",
+                                              "source": "BASELINE.md section 2 (real reference, build container)"}}
+
+
+def latest_traffic(workload_key):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/*traffic*.json), or None."""
+    best = None
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
+        try:
+            d = json.load(open(p))
+            if d.get("workload") == workload_key:
+                best = d
+        except Exception:
+            pass
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--sensors", type=int, default=50)
+    ap.add_argument("--grid", type=int, default=500)
+    ap.add_argument("--exchange", choices=["auto", "none", "allgather"], default="auto")
+    ap.add_argument("--ring", type=int, default=16, help="replay-ring slots used by the bench")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import uavenv_amd as U
+    from uavenv_amd.replay import TransitionRing
+
+    E, n, K, W = args.envs, args.sensors, args.steps, args.warmup
+    env = U.BatchedUAVEnv(E, device=local_rank, env_index_base=rank * E, auto_reset=True, seed=0,
+                          num_sensors=n, grid_size=(args.grid, args.grid))
+    exchange = args.exchange
+    if exchange == "auto":
+        exchange = "allgather" if distributed else "none"
+    ring = TransitionRing(args.ring, E, env.obs_dim, dev, world_size=world, rank=rank)
+    env.reset()
+
+    def one_step():
+        # the kernel writes the observations straight into this rank's slice of the ring slot
+        obs, rew, done = env.step_random(obs_out=ring.local_obs_slot())
+        if exchange == "allgather":
+            ring.commit(env.actions_taken, env.reward32, done)
+        else:
+            ring.head = (ring.head + 1) % ring.capacity
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(W):
+        one_step()
+    ring.drain()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()                       # torch's current stream IS the stream the kernel is launched on
+    for _ in range(K):
+        one_step()
+    ev1.record()
+    ring.drain()
+    barrier()
+    dt = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # Kernel-only launch duration, HIP events on the launch stream around back-to-back launches
+    # (measured on every rank, after the timed region so it cannot perturb it)
+    kern_ms = env.time_steps(min(K, 1000))
+    torch.cuda.synchronize(dev)
+
+    total_env_steps = E * K * world
+    value = total_env_steps / dt
+    B = algorithmic_bytes_per_env_step(n)
+    per_launch_bytes = B * E
+    achieved = per_launch_bytes / (kern_ms * 1e-3) / 1e9
+    workload_key = f"{E}x{n}@{args.grid}"
+    tr = latest_traffic(workload_key)
+    out = {
+        "metric": "env-steps/sec at 4096 envs x 50 sensors (HBM GB/s vs peak in roofline)",
+        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64 state / f32 distances+observations", "data": "synthetic",
+        "config": {"workload": f"{E} envs/GPU x {n} sensors, {args.grid}x{args.grid} grid, BASE_ENV_CONFIG, "
+                               f"uniform-random policy (in-kernel Philox), auto-reset, obs+reward+done written every step",
+                   "envs_per_gpu": E, "sensors": n, "grid": args.grid, "obs_dim": env.obs_dim,
+                   "exchange": ("rccl all_gather of the transition block per step into a shared replay ring"
+                                if exchange == "allgather" else "none (observations written in place into the replay ring)"),
+                   "parallelism": f"env-shard x{world}"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": (tr or {}).get("hbm_bytes_per_launch"),
+                     "kernel": "uav_step_kernel<64>", "algorithmic_bytes_per_launch": per_launch_bytes,
+                     "algorithmic_bytes_per_env_step": B, "avg_launch_ms": kern_ms,
+                     "timed_region_event_ms_per_step": ev_ms / K,
+                     "note": "path is VALU/latency bound (Philox + float64 physics per sensor), not HBM bound: "
+                             "see DESIGN.md"},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(n, (args.grid, args.grid))
+        out["cpu_baseline"]["host"] = {"cpu_count": os.cpu_count()}
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    env.close()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 CSV output into the small files committed under profiles/.
+
+  parse_rocprof.py stats  <dir> <out.md>        kernel-trace + stats pass  -> per-kernel table
+  parse_rocprof.py pmc    <fetch_dir> <write_dir> <workload> <out.json>   PMC passes -> HBM bytes/launch
+
+PMC correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950
+FETCH_SIZE reports HALF of the bytes of a coalesced streaming read, so hbm_bytes =
+(2*FETCH_SIZE + WRITE_SIZE) * 1024.  (The guide calibrates that factor for 16 B/lane accesses; this
+kernel loads 4 and 8 B per lane, so the raw values are kept beside the corrected one.)
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def find(d, suffix):
+    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
+    return hits
+
+
+def stats(d, out):
+    rows = []
+    for p in find(d, "kernel_trace.csv"):
+        with open(p) as f:
+            rows += list(csv.DictReader(f))
+    agg = defaultdict(list)
+    meta = {}
+    for r in rows:
+        name = r.get("Kernel_Name", "?")
+        dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        agg[name].append(dur)
+        meta[name] = (r.get("VGPR_Count", r.get("Arch_VGPR_Count", "?")), r.get("SGPR_Count", "?"),
+                      r.get("LDS_Block_Size", "?"), r.get("Scratch_Size", "?"), r.get("Grid_Size", "?"),
+                      r.get("Workgroup_Size", "?"))
+    total = sum(sum(v) for v in agg.values()) or 1
+    lines = ["| kernel | calls | total ms | avg us | min us | max us | % | VGPR | SGPR | LDS | scratch | grid | wg |",
+             "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+    for name, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        m = meta[name]
+        short = name if len(name) < 90 else name[:87] + "..."
+        lines.append(f"| `{short}` | {len(v)} | {sum(v)/1e6:.3f} | {sum(v)/len(v)/1e3:.3f} | {min(v)/1e3:.3f} | "
+                     f"{max(v)/1e3:.3f} | {100*sum(v)/total:.1f} | {m[0]} | {m[1]} | {m[2]} | {m[3]} | {m[4]} | {m[5]} |")
+    with open(out, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+def pmc_avg(d, counter, kernel_substr):
+    vals = []
+    for p in find(d, "counter_collection.csv"):
+        with open(p) as f:
+            for r in csv.DictReader(f):
+                if r.get("Counter_Name") == counter and kernel_substr in r.get("Kernel_Name", ""):
+                    vals.append(float(r["Counter_Value"]))
+    return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
+
+
+def pmc(fetch_dir, write_dir, workload, out):
+    k = "uav_step_kernel"
+    fetch, nf = pmc_avg(fetch_dir, "FETCH_SIZE", k)
+    write, nw = pmc_avg(write_dir, "WRITE_SIZE", k)
+    res = {"workload": workload, "kernel": k, "FETCH_SIZE_KiB_avg": fetch, "WRITE_SIZE_KiB_avg": write,
+           "dispatches": [nf, nw],
+           "hbm_bytes_per_launch": None if fetch is None or write is None else (2 * fetch + write) * 1024,
+           "raw_bytes_per_launch": None if fetch is None or write is None else (fetch + write) * 1024,
+           "correction": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md HBM section (gfx950 FETCH_SIZE = 1/2)"}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3])
+    else:
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
