@@ -1,0 +1,187 @@
+"""SB3-compatible vectorised environment over the HIP kernel.
+
+`UAVVecEnv` honours the Stable-Baselines3 `VecEnv` contract the reference's trainer relies on
+(agents/dqn/dqn.py:1276-1278, :924, :946): `num_envs`, `observation_space`, `action_space`,
+`reset() -> obs[E, D]`, `step_async(actions)` / `step_wait() -> (obs, rewards, dones, infos)` with
+auto-reset, `infos[i]["terminal_observation"]` and `infos[i]["TimeLimit.truncated"]` on episode
+ends, plus `get_attr / set_attr / env_method / env_is_wrapped / seed / close`.  It replaces
+`DummyVecEnv([Monitor(DomainRandEnv(...))] * 4)`: Monitor's `info["episode"] = {"r", "l", "t"}` and
+DomainRandEnv's `last_episode_stats` are produced by the kernel when an episode ends.
+
+The numpy arrays SB3 wants are host copies made at this outermost adapter only; `step_tensors()`
+is the zero-copy device API for GPU-resident learners.
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import _native as N
+from . import spaces
+from .batched_env import BatchedUAVEnv
+from .gym_env import CURRICULUM_STAGES, MAX_SENSORS_LIMIT
+
+try:  # pragma: no cover
+    from stable_baselines3.common.vec_env import VecEnv as _SB3VecEnv
+except Exception:
+    _SB3VecEnv = None
+
+
+class _VecEnvBase:
+    """Duck-typed stand-in for stable_baselines3.common.vec_env.VecEnv when SB3 is not installed."""
+
+    def __init__(self, num_envs, observation_space, action_space):
+        self.num_envs, self.observation_space, self.action_space = num_envs, observation_space, action_space
+        self.render_mode = None
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+
+_Base = _SB3VecEnv if _SB3VecEnv is not None else _VecEnvBase
+
+
+class UAVVecEnv(_Base):
+    """E UAV-IoT environments behind the SB3 VecEnv interface.
+
+    domain_rand=True reproduces what the reference trainer drives (DomainRandEnv, dqn.py:177-451):
+    curriculum grid sampling, fresh layouts, far start, shaping, Jain's bonus, obs padded to 50 slots.
+    """
+
+    def __init__(self, num_envs, domain_rand=False, curriculum_stage=0, max_sensors_limit=MAX_SENSORS_LIMIT,
+                 device=None, env_index_base=0, **config):
+        flags = 0
+        if domain_rand:
+            flags = N.FLAG_RANDOM_LAYOUT | N.FLAG_FAR_START | N.FLAG_PROX_SHAPING | N.FLAG_JAIN_BONUS
+            config.setdefault("pad_sensors", max_sensors_limit)
+            config.setdefault("grid_choices", CURRICULUM_STAGES[min(curriculum_stage, len(CURRICULUM_STAGES) - 1)][0])
+            config.setdefault("grid_size", CURRICULUM_STAGES[0][0][0])
+        self.env = BatchedUAVEnv(num_envs, device=device, env_index_base=env_index_base, auto_reset=True,
+                                 flags=flags, **config)
+        self._domain_rand = domain_rand
+        self._curriculum_stage = curriculum_stage
+        D = self.env.obs_dim
+        if domain_rand:
+            obs_space = spaces.Box(low=-np.inf, high=np.inf, shape=(D,), dtype=np.float32)      # dqn.py:252-254
+        else:
+            obs_space = spaces.Box(low=np.full(D, -1.0, np.float32), high=np.ones(D, np.float32), dtype=np.float32)
+        super().__init__(num_envs, obs_space, spaces.Discrete(5))
+        self._actions = torch.zeros(num_envs, dtype=torch.int32, device=self.env.device)
+        self._t0 = time.time()
+        self._last_stats = [None] * num_envs
+        self._pending = False
+
+    # ---- SB3 VecEnv contract --------------------------------------------------------------------
+    def reset(self):
+        return self.env.reset().cpu().numpy()
+
+    def step_async(self, actions):
+        a = np.asarray(actions)
+        if a.shape != (self.num_envs,):
+            a = a.reshape(self.num_envs)
+        if ((a < 0) | (a > 4)).any():
+            raise ValueError(f"Invalid action: {a[(a < 0) | (a > 4)][0]}")           # uav_env.py:468
+        self._actions.copy_(torch.from_numpy(a.astype(np.int32)), non_blocking=True)
+        self.env.step(self._actions)                                                  # one kernel launch, async
+        self._pending = True
+
+    def step_wait(self):
+        assert self._pending
+        self._pending = False
+        env = self.env
+        obs = env.obs.cpu().numpy()
+        rews = env.reward32.cpu().numpy()
+        dones = env.done.cpu().numpy().astype(bool)
+        infos = [{} for _ in range(self.num_envs)]
+        if dones.any():
+            idx = np.nonzero(dones)[0]
+            term = env.terminal_obs[torch.from_numpy(idx).to(env.device)].cpu().numpy()
+            stats = env.episode_stats()
+            now = round(time.time() - self._t0, 6)
+            for j, i in enumerate(idx):
+                st = stats[i]
+                info = infos[i]
+                info["terminal_observation"] = term[j]
+                info["TimeLimit.truncated"] = True           # `terminated` is always False (uav_env.py:471)
+                info["episode"] = {"r": float(st["episode_return"]), "l": int(st["length"]), "t": now}
+                les = self._episode_stats_dict(st)
+                info["last_episode_stats"] = les
+                info["total_data_collected"] = les["total_collected"]
+                info["battery"] = les["battery_remaining"]
+                self._last_stats[i] = les
+        return obs, rews, dones, infos
+
+    def step_tensors(self, actions):
+        """Device-resident fast path: int32 cuda tensor in, (obs, reward32, done) cuda tensors out, no sync."""
+        obs, _, done = self.env.step(actions)
+        return obs, self.env.reward32, done
+
+    def _episode_stats_dict(self, st):
+        """dqn.py:316-331 last_episode_stats keys."""
+        tg, tc = float(st["total_generated"]), float(st["total_collected"])
+        used = float(self.env.cfg.max_battery) - float(st["battery_remaining"])
+        cov = int(st["first_full_coverage_step"])
+        return {"total_generated": tg, "total_collected": tc, "total_lost": float(st["total_lost"]),
+                "battery_remaining": float(st["battery_remaining"]),
+                "ndr": int(st["sensors_visited"]) / int(st["num_sensors"]) * 100,
+                "fairness_std": float(st["fairness_std"]), "jains_index": float(st["jains_index"]),
+                "grid_size": (int(st["grid_w"]), int(st["grid_h"])), "num_sensors": int(st["num_sensors"]),
+                "data_efficiency": (tc / tg * 100) if tg > 0 else 0.0,
+                "bytes_per_wh": (tc / used) if used > 0 else 0.0,
+                "time_to_coverage": cov if cov >= 0 else None}
+
+    def close(self):
+        self.env.close()
+
+    def seed(self, seed=None):
+        if seed is not None:
+            self.env.seed(seed)
+        return [None if seed is None else seed + i for i in range(self.num_envs)]
+
+    def _indices(self, indices):
+        if indices is None:
+            return list(range(self.num_envs))
+        if isinstance(indices, int):
+            return [indices]
+        return list(indices)
+
+    def get_attr(self, attr_name, indices=None):
+        idx = self._indices(indices)
+        if attr_name == "last_episode_stats":                                         # dqn.py:924
+            return [self._last_stats[i] for i in idx]
+        rec = None
+        if attr_name in ("current_step", "total_reward", "total_data_collected", "boundary_hits", "edge_steps"):
+            rec = self.env.records()
+            return [rec[attr_name][i].item() for i in idx]
+        if attr_name == "num_sensors":
+            return [int(self.env.records()["num_sensors"][i]) for i in idx]
+        if attr_name == "grid_size":
+            rec = self.env.records()
+            return [(int(rec["grid_w"][i]), int(rec["grid_h"][i])) for i in idx]
+        if attr_name == "render_mode":
+            return [None for _ in idx]
+        if hasattr(self, attr_name):
+            return [getattr(self, attr_name) for _ in idx]
+        raise AttributeError(attr_name)
+
+    def set_attr(self, attr_name, value, indices=None):
+        raise AttributeError(f"UAVVecEnv has no settable per-env attribute {attr_name!r}")
+
+    def env_method(self, method_name, *method_args, indices=None, **method_kwargs):
+        idx = self._indices(indices)
+        if method_name == "set_curriculum_stage":                                     # dqn.py:946
+            stage = int(np.clip(method_args[0], 0, len(CURRICULUM_STAGES) - 1))
+            self._curriculum_stage = stage
+            self.env.set_grid_choices(CURRICULUM_STAGES[stage][0])
+            return [None for _ in idx]
+        raise AttributeError(method_name)
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False for _ in self._indices(indices)]
+
+    def get_images(self):
+        return [None] * self.num_envs
+
+    def render(self, mode=None):
+        return None

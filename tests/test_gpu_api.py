@@ -1,0 +1,174 @@
+"""GPU: the host-side mirrors of the reference interfaces (gymnasium-style UAVEnvironment,
+DomainRandEnv, SB3-style UAVVecEnv) against the oracle, written like tests the reference could hold."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+INFO_KEYS = {"uav_position", "battery", "battery_percent", "sensors_collected", "current_step", "total_reward",
+             "total_data_collected", "coverage_percentage", "is_alive", "max_urgency", "avg_urgency",
+             "high_urgency_sensors", "capture_effect_triggers", "boundary_hits", "edge_steps",
+             "last_step_bytes_collected", "sensor_collection_ratios"}          # uav_env.py:676-700
+
+
+def _mods():
+    import torch
+    import uavenv_amd as U
+    from oracle import oracle as O
+    return torch, U, O
+
+
+def test_gym_env_api_matches_oracle():
+    torch, U, O = _mods()
+    kw = dict(grid_size=(120, 120), num_sensors=20, max_steps=60, sensor_duty_cycle=70.0)
+    env = U.UAVEnvironment(seed=5, env_index=3, **kw)
+    assert env.action_space.n == 5 and env.observation_space.shape == (63,)
+    assert env.observation_space.dtype == np.float32
+    orc = O.OracleEnv(O.default_config(grid_size=(120, 120), num_sensors=20, max_steps=60, duty_cycle=70.0, seed=5), 3)
+    obs, info = env.reset()
+    assert obs.dtype == np.float32 and obs.shape == (63,) and set(info) == INFO_KEYS
+    assert np.array_equal(obs, orc.reset_keyed())
+    assert np.array_equal(env.uav.position, np.zeros(2, np.float32)) and env.uav.battery == 274.0
+    rng = np.random.default_rng(0)
+    total = 0.0
+    for s in range(130):
+        a = int(rng.integers(0, 5))
+        obs, r, term, trunc, info = env.step(a)
+        oo, rr, tr = orc.step_keyed(a)
+        assert term is False and isinstance(r, float) and isinstance(trunc, bool)
+        assert np.max(np.abs(obs - oo)) <= 1e-6 and abs(r - rr) <= 1e-9 * max(1, abs(rr)) and trunc == tr
+        total += r
+        st = orc.state()
+        assert info["current_step"] == st["step"] and abs(info["battery"] - st["battery"]) < 1e-9
+        assert info["sensors_collected"] == int(st["visited"].sum())
+        assert abs(info["total_data_collected"] - st["total_collected"]) < 1e-6
+        assert len(info["sensor_collection_ratios"]) == 20
+        if s % 25 == 0:      # attribute reads the reference's callers perform
+            assert env.sensors[3].spreading_factor == st["sf"][3]
+            assert abs(env.sensors[3].data_buffer - st["buffer"][3]) < 1e-9
+            assert env.sensors_visited == set(np.nonzero(st["visited"])[0].tolist())
+            assert env.current_step == st["step"] and abs(env.total_data_collected - st["total_collected"]) < 1e-6
+            assert np.array_equal(env.uav.position, np.array([st["uav_x"], st["uav_y"]], np.float32))
+            assert env.uav.is_alive() == (st["battery"] > 0.02 * 274.0)
+        if trunc:
+            obs, info = env.reset()
+            assert np.array_equal(obs, orc.reset_keyed())
+            assert env.current_step == 0 and env.sensors_visited == set()
+    env.close()
+
+
+def test_gym_env_invalid_action_raises_after_ageing():
+    torch, U, O = _mods()
+    env = U.UAVEnvironment(grid_size=(50, 50), num_sensors=4)
+    env.reset(seed=1)
+    g0 = [s.total_data_generated for s in env.sensors]
+    with pytest.raises(ValueError):
+        env.step(5)
+    assert env.current_step == 1 and all(s.total_data_generated > g for s, g in zip(env.sensors, g0))
+    obs, r, te, tr, info = env.step(4)          # still usable afterwards
+    assert obs.shape == (15,)
+    env.close()
+
+
+def test_explicit_sensor_positions_and_reseed():
+    torch, U, O = _mods()
+    pos = [(10.0, 10.0), (40.5, 12.25), (25.0, 45.0)]
+    env = U.UAVEnvironment(grid_size=(50, 50), sensor_positions=pos, uav_start_position=(25, 25))
+    o1, _ = env.reset(seed=9)
+    assert env.num_sensors == 3 and env.sensor_positions == pos
+    a = [env.step(4)[0] for _ in range(5)]
+    o2, _ = env.reset(seed=9)
+    b = [env.step(4)[0] for _ in range(5)]
+    env2 = U.UAVEnvironment(grid_size=(50, 50), sensor_positions=pos, uav_start_position=(25, 25))
+    o3, _ = env2.reset(seed=9)
+    c = [env2.step(4)[0] for _ in range(5)]
+    assert np.array_equal(o1, o3) and all(np.array_equal(x, y) for x, y in zip(a, c))   # ... same seed+episode => same run
+    env.close(); env2.close()
+
+
+def test_domain_rand_env_matches_oracle_flags():
+    torch, U, O = _mods()
+    base = dict(max_steps=50, sensor_duty_cycle=60.0)
+    env = U.DomainRandEnv(fixed_num_sensors=20, curriculum_stage=2, base_config=base, seed=12, env_index=40)
+    assert env.observation_space.shape == (153,)
+    ocfg = O.default_config(num_sensors=20, pad_sensors=50, max_steps=50, duty_cycle=60.0, seed=12, flags=1 | 2 | 4 | 8,
+                            grid_size=(100, 100), grid_choices=[(100, 100), (200, 200), (300, 300)])
+    orc = O.OracleEnv(ocfg, 40)
+    obs, info = env.reset()
+    assert np.array_equal(obs, orc.reset_keyed())
+    assert env.grid_size == (int(orc.e.grid_w), int(orc.e.grid_h)) and env.grid_size in [(100, 100), (200, 200), (300, 300)]
+    assert np.all(obs[3 + 3 * 20:] == 0)                    # ghost slots (dqn.py:286-298)
+    assert env.last_episode_stats is None
+    rng = np.random.default_rng(1)
+    for s in range(120):
+        a = int(rng.integers(0, 5))
+        obs, r, te, tr, info = env.step(a)
+        oo, rr, otr = orc.step_keyed(a)
+        assert np.max(np.abs(obs - oo)) <= 1e-6 and abs(r - rr) <= 1e-9 * max(1, abs(rr)) and tr == otr
+        if tr:
+            st = orc.state()
+            obs, info = env.reset()
+            assert np.array_equal(obs, orc.reset_keyed())
+            les = env.last_episode_stats
+            assert les is not None and les["num_sensors"] == 20
+            assert abs(les["total_collected"] - st["tx"].sum()) < 1e-6
+            assert abs(les["ndr"] - st["visited"].sum() / 20 * 100) < 1e-9
+    env.set_curriculum_stage(0)
+    for _ in range(60):
+        _, _, _, tr, _ = env.step(0)
+        if tr:
+            env.reset()
+            assert env.grid_size == (100, 100)
+            break
+    env.close()
+
+
+def test_vec_env_sb3_contract():
+    torch, U, O = _mods()
+    E = 6
+    venv = U.UAVVecEnv(E, num_sensors=10, grid_size=(80, 80), max_steps=20, sensor_duty_cycle=100.0, seed=4)
+    assert venv.num_envs == E and venv.action_space.n == 5 and venv.observation_space.shape == (33,)
+    ocfg = O.default_config(num_sensors=10, grid_size=(80, 80), max_steps=20, duty_cycle=100.0, seed=4)
+    envs = [O.OracleEnv(ocfg, k) for k in range(E)]
+    obs = venv.reset()
+    assert obs.shape == (E, 33) and obs.dtype == np.float32
+    for k in range(E):
+        assert np.array_equal(obs[k], envs[k].reset_keyed())
+    rng = np.random.default_rng(2)
+    ep_ret = np.zeros(E)
+    saw_done = False
+    for s in range(45):
+        acts = rng.integers(0, 5, size=E)
+        venv.step_async(acts)
+        obs, rews, dones, infos = venv.step_wait()
+        assert rews.dtype == np.float32 and dones.dtype == bool and len(infos) == E
+        for k in range(E):
+            oo, rr, tr = envs[k].step_keyed(int(acts[k]))
+            ep_ret[k] += rr
+            assert dones[k] == tr and abs(rews[k] - rr) <= 1e-5 * max(1, abs(rr))
+            if tr:
+                saw_done = True
+                assert np.max(np.abs(infos[k]["terminal_observation"] - oo)) <= 1e-6
+                assert infos[k]["TimeLimit.truncated"] is True
+                assert infos[k]["episode"]["l"] == 20
+                assert abs(infos[k]["episode"]["r"] - ep_ret[k]) <= 1e-9 * max(1, abs(ep_ret[k]))
+                assert infos[k]["last_episode_stats"]["num_sensors"] == 10
+                ep_ret[k] = 0.0
+                oo = envs[k].reset_keyed()
+            else:
+                assert infos[k] == {}
+            assert np.max(np.abs(obs[k] - oo)) <= 1e-6
+    assert saw_done
+    assert venv.get_attr("last_episode_stats")[0]["num_sensors"] == 10
+    assert venv.env_is_wrapped(object) == [False] * E
+    with pytest.raises(ValueError):
+        venv.step_async(np.array([0, 1, 2, 3, 4, 5]))
+    venv.close()
+    dr = U.UAVVecEnv(4, domain_rand=True, num_sensors=20, max_steps=15)
+    assert dr.observation_space.shape == (153,)
+    dr.reset()
+    dr.env_method("set_curriculum_stage", 3)
+    for _ in range(20):
+        dr.step(np.zeros(4, dtype=np.int64))
+    assert all(g in [(100, 100), (200, 200), (300, 300), (400, 400)] for g in dr.get_attr("grid_size"))
+    dr.close()

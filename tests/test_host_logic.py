@@ -1,0 +1,109 @@
+"""CPU: host-side logic -- kwargs mapping, spaces, the deterministic tape, the transition ring
+(single process and a 2-rank gloo run of the all-gather path)."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import tape as T
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_reference_kwargs_map_onto_config_fields():
+    import uavenv_amd as U
+    cfg = U.config_from_kwargs(grid_size=(250, 300), num_sensors=33, sensor_duty_cycle=25.0, uav_start_position=(3, 4),
+                               max_battery=100.0, collection_duration=2.0, max_steps=77, penalty_data_loss=-2.0,
+                               reward_urgency_reduction=5.0, penalty_battery=-0.1, reward_movement=1.0,
+                               include_sensor_positions=True, lora_spreading_factor=9, path_loss_exponent=3.3,
+                               render_mode=None, rssi_threshold=-90.0, data_generation_rate=5.0, max_buffer_size=500.0)
+    assert (cfg.grid_w, cfg.grid_h, cfg.num_sensors) == (250, 300, 33)
+    assert (cfg.duty_cycle, cfg.start_x, cfg.start_y) == (25.0, 3.0, 4.0)
+    assert (cfg.max_battery, cfg.collection_duration, cfg.max_steps) == (100.0, 2.0, 77)
+    assert (cfg.penalty_data_loss, cfg.reward_urgency_reduction, cfg.penalty_battery, cfg.reward_movement) == (-2.0, 5.0, -0.1, 1.0)
+    assert cfg.include_sensor_positions == 1 and cfg.rssi_threshold == -90.0
+    assert (cfg.data_generation_rate, cfg.max_buffer_size) == (5.0, 500.0)
+    with pytest.raises(TypeError):
+        U.config_from_kwargs(no_such_field=1)
+
+
+def test_spaces_look_like_gymnasium():
+    from uavenv_amd import spaces
+    a = spaces.Discrete(5)
+    assert a.n == 5 and a.contains(4) and not a.contains(5) and 0 <= a.sample() < 5
+    b = spaces.Box(low=np.full(63, -1.0, np.float32), high=np.ones(63, np.float32), dtype=np.float32)
+    assert b.shape == (63,) and b.dtype == np.float32 and b.contains(b.sample())
+
+
+def test_tape_is_bit_stable():
+    """The fixtures store only `tape_seed`; the tape must never change."""
+    h = hashlib.sha256()
+    h.update(T.step_tape(424242, 3, 17, 50).tobytes())
+    h.update(T.reset_tape(424242, 3, 2, 50).tobytes())
+    px, py = T.positions(424242, 3, 50, 500, 500)
+    h.update(px.tobytes()); h.update(py.tobytes())
+    h.update(T.actions(424242, 3, 100).tobytes())
+    assert h.hexdigest() == "0eb83a6d44671551d0b4d99d7a5b317769f41c398a60b739eacf05ec0e8474c1"
+    st = T.step_tape(1, 0, 0, 4)
+    assert st.dtype == np.float32 and st.shape == (6, 4)
+    assert np.all((st[T.SLOT_U] >= 0) & (st[T.SLOT_U] < 1)) and np.all(np.abs(st[T.SLOT_ZA]) <= 5.0)
+    z = np.concatenate([T.step_tape(5, e, s, 50)[[0, 1, 3, 4, 5]].ravel() for e in range(4) for s in range(20)])
+    assert abs(z.mean()) < 0.05 and abs(z.std() - 1.0206) < 0.03
+
+
+def test_transition_ring_single_rank_cpu():
+    from uavenv_amd.replay import TransitionRing
+    ring = TransitionRing(4, 3, 5, "cpu")
+    for s in range(6):
+        ring.local_obs_slot().fill_(float(s))
+        slot = ring.commit(torch.full((3,), s % 5), torch.full((3,), 10.0 * s), torch.tensor([0, 1, 0]))
+        assert slot == s % 4
+    assert ring.size == 4 and ring.head == 2
+    assert torch.equal(ring.obs[1, 0], torch.full((3, 5), 5.0))         # slot 1 now holds step 5
+    b = ring.sample(64, generator=torch.Generator().manual_seed(0))
+    assert b["obs"].shape == (64, 5) and b["next_obs"].shape == (64, 5)
+    assert torch.all(b["next_obs"][:, 0] == b["obs"][:, 0] + 1)         # successor slot = next step
+    assert torch.equal(b["reward"], b["obs"][:, 0] * 10.0)
+
+
+def _ring_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from uavenv_amd.replay import TransitionRing
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    E, D = 4, 6
+    ring = TransitionRing(3, E, D, "cpu", world_size=world, rank=rank)
+    ok = True
+    for s in range(5):
+        mine = torch.arange(E * D, dtype=torch.float32).reshape(E, D) + 1000 * rank + 100 * s
+        ring.local_obs_slot().copy_(mine)
+        slot = ring.commit(torch.full((E,), rank), torch.full((E,), float(s)), torch.zeros(E))
+        ring.drain()
+        for r in range(world):
+            want = torch.arange(E * D, dtype=torch.float32).reshape(E, D) + 1000 * r + 100 * s
+            ok &= bool(torch.equal(ring.obs[slot, r], want))
+            ok &= bool(torch.equal(ring.aux[slot, r, :, 0], torch.full((E,), float(r))))
+            ok &= bool(torch.equal(ring.aux[slot, r, :, 1], torch.full((E,), float(s))))
+    b = ring.sample(32)
+    ok &= b["obs"].shape == (32, D)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok))
+
+
+def test_transition_ring_allgather_two_ranks_gloo():
+    """The N>1 path of bench.py / BASELINE config 4 on CPU: every rank ends up with every rank's block."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ring_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
