@@ -202,7 +202,7 @@ extern "C" int uavenv_create(const UavEnvConfig* cfg, int32_t num_envs, uint32_t
     e->ptrs.lost = (double*)(base + o_l); e->ptrs.avg = (double*)(base + o_a); e->ptrs.flags = (uint32_t*)(base + o_f);
     e->ptrs.rec = (UavEnvRecord*)(base + o_r); e->ptrs.stats = (UavEnvEpisodeStats*)(base + o_s);
     e->ptrs.status = (uint32_t*)(base + o_st);
-    e->ptrs.step_tape = nullptr; e->ptrs.reset_tape = nullptr;
+    e->ptrs.step_tape = nullptr; e->ptrs.reset_tape = nullptr; e->ptrs.stamps = nullptr;
     st = hipMemset(e->block, 0, off);
     if (st != hipSuccess) return bail(UAVENV_E_HIP, std::string("hipMemset: ") + hipGetErrorString(st));
     st = launch_init(e->G, e->padded_envs, e->consts, e->ptrs, env_index_base, cfg->grid_w, cfg->grid_h, cfg->num_sensors,
@@ -398,3 +398,12 @@ extern "C" int uavenv_time_steps(UavEnv* e, int32_t steps, float* obs, double* r
     *avg_ms = ms / (float)steps;
     return UAVENV_OK;
 }
+
+#ifdef UAVENV_STAMPS
+// diagnostic build only: in-kernel timestamps (8 x uint64 per wavefront of the step kernel)
+extern "C" int uavenv_debug_set_stamps(UavEnv* e, unsigned long long* stamps_dev) {
+    if (!e) return UAVENV_E_INVALID;
+    e->ptrs.stamps = stamps_dev;
+    return UAVENV_OK;
+}
+#endif

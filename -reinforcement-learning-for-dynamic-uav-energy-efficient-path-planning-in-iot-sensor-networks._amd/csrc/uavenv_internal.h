@@ -46,6 +46,7 @@ struct Ptrs {
     const float* step_tape;     // [E][6][G] or nullptr
     const float* reset_tape;    // [E][3][G] or nullptr
     uint32_t* status;           // device word: OR of per-env status bits
+    unsigned long long* stamps; // diagnostic build only (-DUAVENV_STAMPS): 8 words per wavefront, else unused
 };
 
 struct StepArgs {

@@ -33,21 +33,54 @@ namespace uavenv {
 template <int G> __device__ __forceinline__ int group_base() { return (int)(threadIdx.x & 63u) & ~(G - 1); }
 template <int G> __device__ __forceinline__ int group_lane() { return (int)(threadIdx.x & (unsigned)(G - 1)); }
 
-template <int G> __device__ __forceinline__ double gsum(double v) {
-#pragma unroll
-    for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+// DPP lane exchanges (no LDS crossbar, no address VGPR).  The four controls below form an xor-like
+// butterfly inside a 16-lane row when applied in this order: quad_perm[1,0,3,2], quad_perm[2,3,0,1],
+// row_half_mirror, row_mirror -- after step k every lane of an aligned 2^k block holds the same value,
+// so the mirrors exchange with the OTHER half.  Every lane of a row ends with the identical bits
+// (each addition is commutative and the tree is the same for all lanes).
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
+
+template <int CTRL> __device__ __forceinline__ float dpp(float v) {
+    int i = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(i, i, CTRL, 0xF, 0xF, false));
+}
+template <int CTRL> __device__ __forceinline__ double dpp(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane(double v, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float readlane(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+struct OpSum { template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return a + b; } };
+struct OpMax { template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return b > a ? b : a; } };
+struct OpMin { template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return b < a ? b : a; } };
+
+// all-lanes reduction over a lane group: 4 DPP steps inside each 16-lane row, then rows are
+// combined with one bpermute level (G = 32) or through SGPRs with v_readlane (G = 64: the group is
+// the whole wave, so the result is wave-uniform).
+template <int G, typename T, typename Op> __device__ __forceinline__ T greduce(T v, Op op) {
+    v = op(v, dpp<kDppXor1>(v));
+    v = op(v, dpp<kDppXor2>(v));
+    v = op(v, dpp<kDppHalfMirror>(v));
+    v = op(v, dpp<kDppMirror>(v));
+    if (G == 32) v = op(v, __shfl_xor(v, 16, 64));
+    if (G == 64) {
+        T r0 = readlane(v, 0), r1 = readlane(v, 16), r2 = readlane(v, 32), r3 = readlane(v, 48);
+        v = op(op(r0, r1), op(r2, r3));
+    }
     return v;
 }
-template <int G> __device__ __forceinline__ double gmax(double v) {
-#pragma unroll
-    for (int m = G / 2; m >= 1; m >>= 1) { double o = __shfl_xor(v, m, 64); v = o > v ? o : v; }
-    return v;
-}
-template <int G> __device__ __forceinline__ float gmin_f32(float v) {
-#pragma unroll
-    for (int m = G / 2; m >= 1; m >>= 1) { float o = __shfl_xor(v, m, 64); v = o < v ? o : v; }
-    return v;
-}
+template <int G> __device__ __forceinline__ double gsum(double v) { return greduce<G>(v, OpSum()); }
+template <int G> __device__ __forceinline__ double gmax(double v) { return greduce<G>(v, OpMax()); }
+template <int G> __device__ __forceinline__ float gmin_f32(float v) { return greduce<G>(v, OpMin()); }
 // ballot restricted to this lane's group, shifted so bit k = group lane k
 template <int G> __device__ __forceinline__ uint64_t gballot(bool pred) {
     uint64_t b = __ballot(pred);
@@ -56,6 +89,15 @@ template <int G> __device__ __forceinline__ uint64_t gballot(bool pred) {
 }
 template <int G> __device__ __forceinline__ bool gany(bool pred) { return gballot<G>(pred) != 0ull; }
 template <int G, typename T> __device__ __forceinline__ T gshfl(T v, int src) { return __shfl(v, group_base<G>() + src, 64); }
+// same, for a source lane that is uniform over the group: a scalar v_readlane when the group is the wave
+template <int G> __device__ __forceinline__ double gbcast(double v, int src) {
+    if (G == 64) return readlane(v, __builtin_amdgcn_readfirstlane(src));
+    return gshfl<G>(v, src);
+}
+template <int G> __device__ __forceinline__ uint32_t gbcast(uint32_t v, int src) {
+    if (G == 64) return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(src));
+    return gshfl<G>(v, src);
+}
 
 // numpy float32 add.reduce order (pairwise sum, n <= 64 < PW_BLOCKSIZE): 8 strided accumulators
 // combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then a sequential tail; plain loop for n < 8.
@@ -108,7 +150,11 @@ __device__ __forceinline__ double rssi_deterministic(const Consts& c, float ux, 
     float dy = (uy - sy) * 10.0f;
     float ground = sqrt_rn(dx * dx + dy * dy);
     float d = sqrt_rn(ground * ground + c.alt2);
+#ifdef UAV_ABL_LOG10       // timing-only ablation build
+    float l10 = __log10f(d);
+#else
     float l10 = (float)log10((double)d);
+#endif
     double path_loss;
     if ((double)d < c.d_break) {
         float t = 20.0f * l10;
@@ -139,6 +185,20 @@ __device__ __forceinline__ double calc_urgency(const Consts& c, double b, double
     double loss_rate = gen > 0 ? lost / gen : 0.0;
     double u = util * (1.0 + loss_rate * 10.0);
     return u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
+}
+
+// When the lane group is the whole wavefront (G = 64) the environment record is wave-uniform: moving it to
+// SGPRs frees ~32 VGPRs and lets the compiler run the per-environment integer work on the scalar ALU.
+template <int G> __device__ __forceinline__ UavEnvRecord load_record(const UavEnvRecord* rec, size_t env) {
+    UavEnvRecord r = rec[env];
+    if (G == 64) {
+        union { UavEnvRecord r; int w[32]; } u;
+        u.r = r;
+#pragma unroll
+        for (int i = 0; i < 32; i++) u.w[i] = __builtin_amdgcn_readfirstlane(u.w[i]);
+        r = u.r;
+    }
+    return r;
 }
 
 // per-lane sensor registers
@@ -277,7 +337,10 @@ __device__ __forceinline__ void reset_group(const Consts& c, const Ptrs& p, Sens
     if ((c.flags & UAVENV_FLAG_RANDOM_LAYOUT) && c.n_grid_choices > 0) {          // dqn.py:334
         Words4 w0 = noise_words(c.seed, r.env_index, ep, 0u, 0u, 2);
         int g = (int)(((uint64_t)w0.w3 * (uint32_t)c.n_grid_choices) >> 32);
-        r.grid_w = c.gw[g]; r.grid_h = c.gh[g];
+        int gw = c.gw[0], gh = c.gh[0];
+#pragma unroll
+        for (int k = 1; k < 8; k++) { gw = (g == k) ? c.gw[k] : gw; gh = (g == k) ? c.gh[k] : gh; }
+        r.grid_w = gw; r.grid_h = gh;
     }
     float fill_u = u24(w.w0);
     if (p.reset_tape != nullptr) {
@@ -375,7 +438,7 @@ __global__ __launch_bounds__(kBlockThreads) void uav_reset_kernel(Consts c, Ptrs
     const size_t idx = env * G + gl;
     float* lds_row = lds + (threadIdx.x / G) * c.obs_dim;
 
-    UavEnvRecord r = p.rec[env];
+    UavEnvRecord r = load_record<G>(p.rec, env);
     Sensor s;
     load_sensor<G>(p, idx, s);
     const bool in_batch = env < (size_t)a.num_envs;
@@ -405,15 +468,18 @@ __global__ __launch_bounds__(kBlockThreads) void uav_reset_kernel(Consts c, Ptrs
 // step kernel: the hot path
 // ---------------------------------------------------------------------------------------------
 template <int G>
-__global__ __launch_bounds__(kBlockThreads) void uav_step_kernel(Consts c, Ptrs p, StepArgs a) {
+__global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_kernel(Consts c, Ptrs p, StepArgs a) {
     extern __shared__ float lds[];
+#ifdef UAVENV_STAMPS
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int gl = group_lane<G>();
     const size_t env = (size_t)blockIdx.x * (kBlockThreads / G) + threadIdx.x / G;
     const size_t idx = env * G + gl;
     float* lds_row = lds + (threadIdx.x / G) * c.obs_dim;
     const bool in_batch = env < (size_t)a.num_envs;
 
-    UavEnvRecord r = p.rec[env];
+    UavEnvRecord r = load_record<G>(p.rec, env);
     Sensor s;
     load_sensor<G>(p, idx, s);
     const int n = r.num_sensors;
@@ -429,25 +495,29 @@ __global__ __launch_bounds__(kBlockThreads) void uav_step_kernel(Consts c, Ptrs 
         if (a.actions_out != nullptr && in_batch && gl == 0) a.actions_out[env] = action;
     }
     const bool is_c = action == 4;
-    const bool is_m = action >= 0 && action <= 3;
-    if (!is_c && !is_m) r.status |= 1u;                         // uav_env.py:468 ValueError (after ageing)
+    const bool is_m = (action >= 0) & (action <= 3);
+    r.status |= (!is_c & !is_m) ? 1u : 0u;                      // uav_env.py:468 ValueError (after ageing)
 
     // ---- uav_env.py:439-447: step counter, edge-cell bookkeeping on the PRE-move position --------
     r.current_step += 1;
     {
         double W = (double)r.grid_w, H = (double)r.grid_h, ux = (double)r.uav_x, uy = (double)r.uav_y;
         const double eps = 1e-6;
-        if (ux <= eps || uy <= eps || ux >= W - 1 - eps || uy >= H - 1 - eps) r.edge_steps += 1;
+        const bool edge = (ux <= eps) | (uy <= eps) | (ux >= W - 1 - eps) | (uy >= H - 1 - eps);
+        r.edge_steps += edge ? 1 : 0;
     }
     // ---- :450-459 age all sensors (iot_sensors.py:114-125), data-loss delta ------------------------
     const double step_duration = is_c ? c.coll_dur : 1.0;
     double loss = 0.0;
-    if (act) {
-        double new_data = c.rate * step_duration;
-        s.gen += new_data;
-        double potential = s.b + new_data;
-        if (potential > c.bmax) { loss = potential - c.bmax; s.b = c.bmax; s.lost += loss; }
-        else s.b = potential;
+    {
+        const double new_data = c.rate * step_duration;
+        const double potential = s.b + new_data;
+        const bool over = potential > c.bmax;
+        const double l = over ? potential - c.bmax : 0.0;
+        s.gen = act ? s.gen + new_data : s.gen;
+        s.b = act ? (over ? c.bmax : potential) : s.b;
+        s.lost = (act & over) ? s.lost + l : s.lost;
+        loss = act ? l : 0.0;
     }
     const double step_data_loss = gsum<G>(loss);
 
@@ -455,20 +525,29 @@ __global__ __launch_bounds__(kBlockThreads) void uav_step_kernel(Consts c, Ptrs 
     double reward = 0.0;
 
     // ---- :494-516 move (uav.py:127-185, reward_function.py:69-79); scalar per group ---------------
-    if (is_m) {
-        double battery_before = r.battery;
-        float nx = r.uav_x, ny = r.uav_y;
-        if (action == 0) ny += 1.0f; else if (action == 1) ny -= 1.0f;
-        else if (action == 2) nx -= 1.0f; else nx += 1.0f;
-        bool ok = (0 <= nx && nx < (float)r.grid_w && 0 <= ny && ny < (float)r.grid_h);
-        if (ok) { r.uav_x = nx; r.uav_y = ny; r.battery -= c.e_move; }
-        else { r.battery -= c.e_coll; r.boundary_hits += 1; }
-        double battery_used = battery_before - r.battery;
-        reward = c.p_step;
-        reward += ok ? c.r_move : c.p_boundary;
-        reward += c.p_battery * battery_used;
-        reward += c.p_loss * step_data_loss;
-        r.last_step_bytes = 0.0;
+    // Written branch-free (bitwise &, selects) on purpose: ROCm 7.2's gfx950 backend mis-compiled the
+    // natural `ok = a && b && c && d; if (ok) {..} else {..}` form here (the e_move / r_move selects were
+    // sunk into the `0 <= nx` block only; caught by the parity tests).
+    {
+        const double battery_before = r.battery;
+        const float dxm = action == 2 ? -1.0f : (action == 3 ? 1.0f : 0.0f);
+        const float dym = action == 0 ? 1.0f : (action == 1 ? -1.0f : 0.0f);
+        const float nx = r.uav_x + dxm, ny = r.uav_y + dym;
+        const bool ok = (0.0f <= nx) & (nx < (float)r.grid_w) & (0.0f <= ny) & (ny < (float)r.grid_h);
+        const bool mv = is_m & ok;
+        r.uav_x = mv ? nx : r.uav_x;
+        r.uav_y = mv ? ny : r.uav_y;
+        const double drain = ok ? c.e_move : c.e_coll;
+        const double battery_after = battery_before - drain;
+        const double battery_used = battery_before - battery_after;
+        double rw = c.p_step;
+        rw += ok ? c.r_move : c.p_boundary;
+        rw += c.p_battery * battery_used;
+        rw += c.p_loss * step_data_loss;
+        r.battery = is_m ? battery_after : r.battery;
+        r.boundary_hits += (is_m & !ok) ? 1 : 0;
+        r.last_step_bytes = is_m ? 0.0 : r.last_step_bytes;
+        reward = is_m ? rw : 0.0;
     }
 
     // One deterministic path-loss evaluation per sensor and step: a collect step does not move the
@@ -509,20 +588,19 @@ __global__ __launch_bounds__(kBlockThreads) void uav_step_kernel(Consts c, Ptrs 
         bool lower_same = false, beaten = false;
         while (__any(m != 0ull)) {
             int j = m ? (__ffsll((long long)m) - 1) : 0;
-            double cj = gshfl<G>(cur, j);
-            uint32_t sfj = gshfl<G>(sf, j);
-            if (m != 0ull && attempt && sfj == sf && j != gl) {
-                others += 1;
-                omax = cj > omax ? cj : omax;
-                if (j < gl) lower_same = true;
-                if (cj > cur || (cj == cur && j < gl)) beaten = true;
-            }
+            double cj = gbcast<G>(cur, j);
+            uint32_t sfj = gbcast<G>(sf, j);
+            const bool hit = (m != 0ull) & attempt & (sfj == sf) & (j != gl);
+            others += hit ? 1 : 0;
+            omax = (hit & (cj > omax)) ? cj : omax;
+            lower_same |= hit & (j < gl);
+            beaten |= hit & ((cj > cur) | ((cj == cur) & (j < gl)));
             m &= (m - 1ull);
         }
-        const bool contested = attempt && others > 0;
-        const bool winner = attempt && (others == 0 || (!beaten && cur > (omax + c.cap_thr)));
-        const int collision_count = __popcll(gballot<G>(contested)) - __popcll(gballot<G>(contested && !lower_same));
-        const int captures = __popcll(gballot<G>(winner && contested));
+        const bool contested = attempt & (others > 0);
+        const bool winner = attempt & ((others == 0) | (!beaten & (cur > (omax + c.cap_thr))));
+        const int collision_count = __popcll(gballot<G>(contested)) - __popcll(gballot<G>(contested & !lower_same));
+        const int captures = __popcll(gballot<G>(winner & contested));
         // P4 :575-594 + iot_sensors.py:127-145 collect_data
         double bytes = 0.0;
         bool got = false;
@@ -591,12 +669,10 @@ __global__ __launch_bounds__(kBlockThreads) void uav_step_kernel(Consts c, Ptrs 
     }
 
     // ---- :471-487 truncation + terminal penalties (reward_function.py:59-67) -------------------
-    bool truncated = false;
-    if (!(r.battery > c.alive_level)) truncated = true;                          // uav.py:224
-    if (r.current_step >= c.max_steps) truncated = true;
+    const bool truncated = !(r.battery > c.alive_level) | (r.current_step >= c.max_steps);   // uav.py:224, uav_env.py:477
     const int visited_cnt = __popcll(gballot<G>(act && (s.flags & kVisited)));
     {
-        bool starved = act && s.gen > 0 && (s.tx / s.gen) < c.cr_thr;
+        const bool starved = act & (s.gen > 0) & ((s.tx / s.gen) < c.cr_thr);
         int starved_cnt = __popcll(gballot<G>(starved));
         if (truncated) {
             int unvisited = n - visited_cnt;
@@ -608,7 +684,7 @@ __global__ __launch_bounds__(kBlockThreads) void uav_step_kernel(Consts c, Ptrs 
 
     // ---- observation of the stepped state (side effect: ADR EMA) -------------------------------
     const bool auto_reset = (c.flags & UAVENV_FLAG_AUTO_RESET) != 0;
-    const bool do_reset = truncated && auto_reset;
+    const bool do_reset = truncated & auto_reset;
     {
         float* dst = nullptr;
         if (in_batch) {
@@ -673,6 +749,15 @@ __global__ __launch_bounds__(kBlockThreads) void uav_step_kernel(Consts c, Ptrs 
         p.rec[env] = r;
         if (r.status) atomicOr(p.status, r.status);
     }
+#ifdef UAVENV_STAMPS
+    if (p.stamps != nullptr && (threadIdx.x & 63u) == 0) {
+        unsigned long long* q = p.stamps + ((size_t)blockIdx.x * (kBlockThreads / 64) + threadIdx.x / 64) * 8;
+        q[0] = st_t0; q[1] = __builtin_amdgcn_s_memtime(); q[2] = st_r0; q[3] = __builtin_amdgcn_s_memrealtime();
+        q[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
+        q[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));     // HW_REG_XCC_ID
+        q[6] = (unsigned long long)action; q[7] = 0;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

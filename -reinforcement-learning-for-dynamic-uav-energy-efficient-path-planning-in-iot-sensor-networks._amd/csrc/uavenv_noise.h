@@ -39,9 +39,10 @@ UAV_HD uint32_t mulhi32(uint32_t a, uint32_t b) {
 #endif
 }
 
-UAV_HD Words4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+template <int kRounds>
+UAV_HD Words4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
-    for (int r = 0; r < 10; r++) {
+    for (int r = 0; r < kRounds; r++) {
         const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
         uint32_t hi0 = mulhi32(M0, c0), lo0 = M0 * c0;
         uint32_t hi1 = mulhi32(M1, c2), lo1 = M1 * c2;
@@ -53,7 +54,10 @@ UAV_HD Words4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, 
 }
 
 UAV_HD Words4 noise_words(uint64_t seed, uint32_t env, uint32_t episode, uint32_t step, uint32_t lane, uint32_t call) {
-    return philox4x32_10(env, episode, step, lane | (call << 16), (uint32_t)seed, (uint32_t)(seed >> 32));
+#ifdef UAV_ABL_PHILOX      // timing-only ablation build (tools/ablate.py): fewer rounds for the per-lane draws only
+    if (call <= 1u) return philox4x32<UAV_ABL_PHILOX>(env, episode, step, lane | (call << 16), (uint32_t)seed, (uint32_t)(seed >> 32));
+#endif
+    return philox4x32<10>(env, episode, step, lane | (call << 16), (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
 UAV_HD float u24(uint32_t w) { return (float)(w >> 8) * 0x1p-24f; }      // [0,1), 24 bits, exact
@@ -83,6 +87,9 @@ UAV_HD float sqrt_rn(float x) { return __builtin_sqrtf(x); }
 //   angle:  top 2 bits of (b>>8) choose the quadrant, the low 22 bits the angle in [-pi/4, pi/4);
 //           sin/cos by degree-7/8 minimax polynomials.
 UAV_HD void normal_pair(uint32_t a, uint32_t b, float& z0, float& z1) {
+#ifdef UAV_ABL_NORMAL      // timing-only ablation build
+    z0 = (float)(a >> 8) * 0x1p-23f - 1.0f; z1 = (float)(b >> 8) * 0x1p-23f - 1.0f; return;
+#endif
     uint32_t k = (a >> 8) + 1u;
     float u1 = (float)k * 0x1p-24f;
     uint32_t bits = float_to_bits(u1);
