@@ -18,6 +18,7 @@ using namespace uavenv;
 struct UavEnv {
     UavEnvConfig cfg;
     Consts consts;
+    Consts* dev_consts = nullptr;   // device copy read by the kernels through the constant address space
     Ptrs ptrs;
     int32_t num_envs = 0, padded_envs = 0, G = 64, device = 0;
     uint32_t env_index_base = 0;
@@ -144,12 +145,14 @@ static size_t field_elem_bytes(int field) {
     }
 }
 static void* field_ptr(UavEnv* e, int field) {
+    char* sb = e->ptrs.sensor_base;
+    const uint64_t S = e->ptrs.lanes;
     switch (field) {
-        case UAVENV_F_POS_X: return e->ptrs.pos_x;   case UAVENV_F_POS_Y: return e->ptrs.pos_y;
-        case UAVENV_F_BUFFER: return e->ptrs.buffer; case UAVENV_F_GEN: return e->ptrs.gen;
-        case UAVENV_F_TX: return e->ptrs.tx;         case UAVENV_F_LOST: return e->ptrs.lost;
-        case UAVENV_F_AVG_RSSI: return e->ptrs.avg;  case UAVENV_F_FLAGS: return e->ptrs.flags;
-        case UAVENV_F_RECORD: return e->ptrs.rec;    case UAVENV_F_EPISODE_STATS: return e->ptrs.stats;
+        case UAVENV_F_POS_X: return sb + kOffPosX * S;     case UAVENV_F_POS_Y: return sb + kOffPosY * S;
+        case UAVENV_F_BUFFER: return sb + kOffBuffer * S;  case UAVENV_F_GEN: return sb + kOffGen * S;
+        case UAVENV_F_TX: return sb + kOffTx * S;          case UAVENV_F_LOST: return sb + kOffLost * S;
+        case UAVENV_F_AVG_RSSI: return sb + kOffAvg * S;   case UAVENV_F_FLAGS: return sb + kOffFlags * S;
+        case UAVENV_F_RECORD: return e->ptrs.rec;          case UAVENV_F_EPISODE_STATS: return e->ptrs.stats;
         default: return nullptr;
     }
 }
@@ -187,25 +190,25 @@ extern "C" int uavenv_create(const UavEnvConfig* cfg, int32_t num_envs, uint32_t
     const size_t P = (size_t)e->padded_envs, S = P * (size_t)e->G;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t off = 0;
-    size_t o_px = off; off += al(S * 4);  size_t o_py = off; off += al(S * 4);
-    size_t o_b = off; off += al(S * 8);   size_t o_g = off; off += al(S * 8);  size_t o_t = off; off += al(S * 8);
-    size_t o_l = off; off += al(S * 8);   size_t o_a = off; off += al(S * 8);  size_t o_f = off; off += al(S * 4);
+    size_t o_sens = off; off += al(S * kSensorBytesPerLane);      // pos_x | pos_y | buffer | gen | tx | lost | avg | flags
     size_t o_r = off; off += al(P * sizeof(UavEnvRecord));
     size_t o_s = off; off += al(P * sizeof(UavEnvEpisodeStats));
     size_t o_st = off; off += 256;
+    size_t o_c = off; off += al(sizeof(Consts));
     e->block_bytes = off;
     st = hipMalloc(&e->block, off);
     if (st != hipSuccess) return bail(UAVENV_E_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(st));
     char* base = (char*)e->block;
-    e->ptrs.pos_x = (float*)(base + o_px); e->ptrs.pos_y = (float*)(base + o_py);
-    e->ptrs.buffer = (double*)(base + o_b); e->ptrs.gen = (double*)(base + o_g); e->ptrs.tx = (double*)(base + o_t);
-    e->ptrs.lost = (double*)(base + o_l); e->ptrs.avg = (double*)(base + o_a); e->ptrs.flags = (uint32_t*)(base + o_f);
+    e->ptrs.sensor_base = base + o_sens; e->ptrs.lanes = S;
     e->ptrs.rec = (UavEnvRecord*)(base + o_r); e->ptrs.stats = (UavEnvEpisodeStats*)(base + o_s);
     e->ptrs.status = (uint32_t*)(base + o_st);
+    e->dev_consts = (Consts*)(base + o_c);
     e->ptrs.step_tape = nullptr; e->ptrs.reset_tape = nullptr; e->ptrs.stamps = nullptr;
     st = hipMemset(e->block, 0, off);
     if (st != hipSuccess) return bail(UAVENV_E_HIP, std::string("hipMemset: ") + hipGetErrorString(st));
-    st = launch_init(e->G, e->padded_envs, e->consts, e->ptrs, env_index_base, cfg->grid_w, cfg->grid_h, cfg->num_sensors,
+    if (st == hipSuccess) st = hipMemcpy(e->dev_consts, &e->consts, sizeof(Consts), hipMemcpyHostToDevice);
+    if (st != hipSuccess) return bail(UAVENV_E_HIP, std::string("consts upload: ") + hipGetErrorString(st));
+    st = launch_init(e->G, e->padded_envs, e->consts, e->dev_consts, e->ptrs, env_index_base, cfg->grid_w, cfg->grid_h, cfg->num_sensors,
                      (float)cfg->start_x, (float)cfg->start_y, nullptr);
     if (st == hipSuccess) st = hipDeviceSynchronize();
     if (st != hipSuccess) return bail(UAVENV_E_HIP, std::string("init kernel: ") + hipGetErrorString(st));
@@ -250,15 +253,22 @@ extern "C" int uavenv_set_env_params(UavEnv* e, const int32_t* gw, const int32_t
 extern "C" int uavenv_set_positions(UavEnv* e, const float* px, const float* py) {
     if (!e || !px || !py) return UAVENV_E_INVALID;
     size_t bytes = (size_t)e->num_envs * e->G * 4;
-    HIP_TRY(e, hipMemcpy(e->ptrs.pos_x, px, bytes, hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(e->ptrs.pos_y, py, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(field_ptr(e, UAVENV_F_POS_X), px, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(field_ptr(e, UAVENV_F_POS_Y), py, bytes, hipMemcpyHostToDevice));
+    return UAVENV_OK;
+}
+
+// The kernels of earlier launches may still be reading the constants: order the update behind them.
+static int upload_consts(UavEnv* e) {
+    HIP_TRY(e, hipDeviceSynchronize());
+    HIP_TRY(e, hipMemcpy(e->dev_consts, &e->consts, sizeof(Consts), hipMemcpyHostToDevice));
     return UAVENV_OK;
 }
 
 extern "C" int uavenv_set_seed(UavEnv* e, uint64_t seed) {
     if (!e) return UAVENV_E_INVALID;
     e->cfg.seed = seed; e->consts.seed = seed;
-    return UAVENV_OK;
+    return upload_consts(e);
 }
 
 extern "C" int uavenv_set_grid_choices(UavEnv* e, int32_t count, const int32_t* w, const int32_t* h) {
@@ -269,7 +279,7 @@ extern "C" int uavenv_set_grid_choices(UavEnv* e, int32_t count, const int32_t* 
         e->cfg.grid_choices_w[i] = e->consts.gw[i] = w[i];
         e->cfg.grid_choices_h[i] = e->consts.gh[i] = h[i];
     }
-    return UAVENV_OK;
+    return upload_consts(e);
 }
 
 extern "C" int uavenv_set_noise_tape(UavEnv* e, const float* step_tape_dev, const float* reset_tape_dev) {
@@ -280,7 +290,7 @@ extern "C" int uavenv_set_noise_tape(UavEnv* e, const float* step_tape_dev, cons
 
 extern "C" int uavenv_dump_noise(UavEnv* e, float* step_tape_out, float* reset_tape_out, void* stream) {
     if (!e) return UAVENV_E_INVALID;
-    HIP_TRY(e, launch_dump_noise(e->G, e->padded_envs, e->consts, e->ptrs, step_tape_out, reset_tape_out, e->num_envs,
+    HIP_TRY(e, launch_dump_noise(e->G, e->padded_envs, e->consts, e->dev_consts, e->ptrs, step_tape_out, reset_tape_out, e->num_envs,
                                  (hipStream_t)stream));
     return UAVENV_OK;
 }
@@ -288,7 +298,7 @@ extern "C" int uavenv_dump_noise(UavEnv* e, float* step_tape_out, float* reset_t
 extern "C" int uavenv_reset(UavEnv* e, const uint8_t* mask_dev, float* obs_out_dev, void* stream) {
     if (!e) return UAVENV_E_INVALID;
     ResetArgs a{mask_dev, obs_out_dev, e->num_envs};
-    HIP_TRY(e, launch_reset(e->G, e->padded_envs, e->consts, e->ptrs, a, (hipStream_t)stream));
+    HIP_TRY(e, launch_reset(e->G, e->padded_envs, e->consts, e->dev_consts, e->ptrs, a, (hipStream_t)stream));
     return UAVENV_OK;
 }
 
@@ -296,7 +306,7 @@ static int step_common(UavEnv* e, const int32_t* actions, int32_t* actions_out, 
                        uint8_t* done, float* term, void* stream) {
     if (!e) return UAVENV_E_INVALID;
     StepArgs a{actions, actions_out, obs, rew, rew32, done, term, e->num_envs};
-    HIP_TRY(e, launch_step(e->G, e->padded_envs, e->consts, e->ptrs, a, (hipStream_t)stream));
+    HIP_TRY(e, launch_step(e->G, e->padded_envs, e->consts, e->dev_consts, e->ptrs, a, (hipStream_t)stream));
     return UAVENV_OK;
 }
 

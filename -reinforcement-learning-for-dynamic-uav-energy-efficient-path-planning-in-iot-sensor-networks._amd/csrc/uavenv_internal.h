@@ -13,34 +13,46 @@ constexpr int kBlockThreads = 256;          // 4 wavefronts per workgroup
 // flag word per sensor (UAVENV_F_FLAGS)
 constexpr uint32_t kSfMask = 15u, kAvgValid = 16u, kVisited = 32u, kDataCollected = 64u;
 
-// Host-precomputed constants, passed to every kernel BY VALUE (kernarg segment -> SGPRs).
+// Host-precomputed constants, passed to every kernel BY VALUE (kernarg segment -> scalar loads).
 // Each derived value is computed on the host with the reference's own expression, cited.
+// Field order = order of use in the step kernel (every-step fields first, then collect-only, then
+// truncation/reset-only), so the scalar loads that fetch them do not drag cold fields into SGPRs.
 struct Consts {
+    // ---- every step ------------------------------------------------------------------------
     uint64_t seed;
-    double rate, bmax, thr, p_cycle, maxb, coll_dur;
-    double sigma, lambda, one_minus_lambda, tx_power, noise_floor, cap_thr;
+    double rate, bmax, thr;
+    double sigma, lambda, one_minus_lambda, tx_power;
     double d_break;        // iot_sensors.py:174  (4*pi*ht*hr)/0.345
     double c_fs;           // iot_sensors.py:179  20*log10(868)
     double fspl_off;       //                     28
     double c_ht, c_hr;     // iot_sensors.py:183  20*log10(ht), 20*log10(hr)
     double sf_thr[4];
-    double fill_lo, fill_span;
-    double e_move, e_coll, e_hover;   // uav.py:176,180,204  (P*t)/3600
-    double used_hover;                // uav_env.py:530      (P_hover/3600)*duration
-    double alive_level;               // uav.py:224          0.02*max_battery
-    double r_byte, r_new, r_done, r_urg, r_move, p_revisit, p_boundary, p_collision, p_battery,
-           p_hover, p_step, p_loss, p_starvation, p_unvisited, p_starved, cr_thr;
-    double min_start_dist, prox_eta, jain_weight;
-    float  alt2;                      // iot_sensors.py:164  altitude**2 as float32
-    int32_t max_steps, fps, obs_dim, max_tries, use_ema, n_grid_choices;
+    double maxb;
+    double alive_level;    // uav.py:224          0.02*max_battery
+    double e_move, e_coll; // uav.py:176,180      (P*t)/3600
+    double p_step, r_move, p_boundary, p_battery, p_loss;
+    float  alt2;           // iot_sensors.py:164  altitude**2 as float32
+    int32_t max_steps, fps, obs_dim, use_ema;
     uint32_t flags;
+    // ---- collect steps -----------------------------------------------------------------------
+    double coll_dur, p_cycle, noise_floor, cap_thr;
+    double e_hover;        // uav.py:204          (P_hover*duration)/3600
+    double used_hover;     // uav_env.py:530      (P_hover/3600)*duration
+    double r_byte, r_new, r_done, r_urg, p_revisit, p_collision, p_hover, p_starvation;
+    // ---- truncation / reset / DomainRand extras --------------------------------------------------
+    double p_unvisited, p_starved, cr_thr;
+    double fill_lo, fill_span;
+    double min_start_dist, prox_eta, jain_weight;
+    int32_t max_tries, n_grid_choices;
     int32_t gw[8], gh[8];
 };
 
+// All per-sensor arrays live in ONE allocation, array k at byte offset kOff_k * S where
+// S = padded_envs * G lanes:  pos_x 0, pos_y 4, buffer 8, gen 16, tx 24, lost 32, avg 40, flags 48 (x S bytes).
+// One base pointer (+ S) instead of eight pointers keeps the kernel's SGPR budget for constants.
 struct Ptrs {
-    float *pos_x, *pos_y;
-    double *buffer, *gen, *tx, *lost, *avg;
-    uint32_t* flags;
+    char* sensor_base;
+    uint64_t lanes;             // S
     UavEnvRecord* rec;
     UavEnvEpisodeStats* stats;
     const float* step_tape;     // [E][6][G] or nullptr
@@ -48,6 +60,8 @@ struct Ptrs {
     uint32_t* status;           // device word: OR of per-env status bits
     unsigned long long* stamps; // diagnostic build only (-DUAVENV_STAMPS): 8 words per wavefront, else unused
 };
+constexpr uint64_t kOffPosX = 0, kOffPosY = 4, kOffBuffer = 8, kOffGen = 16, kOffTx = 24, kOffLost = 32, kOffAvg = 40,
+                   kOffFlags = 48, kSensorBytesPerLane = 52;
 
 struct StepArgs {
     const int32_t* actions;     // nullptr => in-kernel random policy
@@ -67,11 +81,11 @@ struct ResetArgs {
 };
 
 // launchers (uavenv_kernels.hip)
-hipError_t launch_init(int G, int padded_envs, const Consts& c, const Ptrs& p, uint32_t env_index_base,
+hipError_t launch_init(int G, int padded_envs, const Consts& c, const Consts* dev_consts, const Ptrs& p, uint32_t env_index_base,
                        int32_t grid_w, int32_t grid_h, int32_t n, float start_x, float start_y, hipStream_t s);
-hipError_t launch_reset(int G, int padded_envs, const Consts& c, const Ptrs& p, const ResetArgs& a, hipStream_t s);
-hipError_t launch_step(int G, int padded_envs, const Consts& c, const Ptrs& p, const StepArgs& a, hipStream_t s);
-hipError_t launch_dump_noise(int G, int padded_envs, const Consts& c, const Ptrs& p, float* step_tape,
+hipError_t launch_reset(int G, int padded_envs, const Consts& c, const Consts* dev_consts, const Ptrs& p, const ResetArgs& a, hipStream_t s);
+hipError_t launch_step(int G, int padded_envs, const Consts& c, const Consts* dev_consts, const Ptrs& p, const StepArgs& a, hipStream_t s);
+hipError_t launch_dump_noise(int G, int padded_envs, const Consts& c, const Consts* dev_consts, const Ptrs& p, float* step_tape,
                              float* reset_tape, int32_t num_envs, hipStream_t s);
 
 }  // namespace uavenv

@@ -27,6 +27,12 @@
 
 namespace uavenv {
 
+// The constants live in device memory and are read through the CONSTANT address space: scalar loads
+// (s_load) issued where a field is used.  (Passing the 600-byte struct by value makes the compiler load
+// every field in the entry block and then spill ~80 SGPRs to VGPR lanes.)
+typedef const __attribute__((address_space(4))) Consts& CRef;
+#define UAV_CONSTS(ptr) CRef c = *(const __attribute__((address_space(4))) Consts*)(ptr)
+
 // ---------------------------------------------------------------------------------------------
 // lane-group primitives (G lanes of a wave64)
 // ---------------------------------------------------------------------------------------------
@@ -41,13 +47,13 @@ template <int G> __device__ __forceinline__ int group_lane() { return (int)(thre
 constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
 
 template <int CTRL> __device__ __forceinline__ float dpp(float v) {
-    int i = __float_as_int(v);
-    return __int_as_float(__builtin_amdgcn_update_dpp(i, i, CTRL, 0xF, 0xF, false));
+    // old = 0 + bound_ctrl: every source lane of these controls is valid, so no tied copy of `v` is needed
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 template <int CTRL> __device__ __forceinline__ double dpp(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double readlane(double v, int lane) {
@@ -105,6 +111,26 @@ template <int G> __device__ __forceinline__ uint32_t gbcast(uint32_t v, int src)
 template <int G> __device__ __forceinline__ float np_sum_f32(float a, int n) {
     const int gl = group_lane<G>();
     const int n8 = n - (n & 7);
+    if (G == 64) {
+        // The addends are zero except for the (at most six) sensors drained this step, and x + 0.0f == x
+        // exactly, so only the non-zero lanes matter -- visited in numpy's order: strided accumulators
+        // (lane j of `r` is accumulator j), the pairwise tree, then the sequential tail.
+        const uint64_t nz = __ballot(a != 0.0f);
+        if (nz == 0ull) return 0.0f;
+        const uint64_t body = (n >= 8) ? (n8 >= 64 ? ~0ull : ((1ull << n8) - 1ull)) : 0ull;
+        float r = 0.0f;
+        for (uint64_t m = nz & body; m != 0ull; m &= m - 1ull) {
+            const int i = __ffsll((long long)m) - 1;
+            const float v = readlane(a, i);
+            r = (gl == (i & 7)) ? r + v : r;
+        }
+        r += dpp<kDppXor1>(r);
+        r += dpp<kDppXor2>(r);
+        r += dpp<kDppHalfMirror>(r);
+        float res = (n >= 8) ? readlane(r, 0) : 0.0f;
+        for (uint64_t m = nz & ~body; m != 0ull; m &= m - 1ull) res += readlane(a, __ffsll((long long)m) - 1);
+        return res;
+    }
     float r = a;
 #pragma unroll
     for (int k = 1; k < G / 8; k++) {
@@ -145,16 +171,41 @@ __device__ __forceinline__ double sf_link_quality(uint32_t sf) {
 // float64, exactly the reference's mix.  log10 of the float32 distance is evaluated in float64 and
 // rounded once, i.e. the correctly rounded float32 log10 (the reference's own np.log10(float32) is
 // platform dependent at the 1-ulp level; see oracle/uavenv_oracle.h).
-__device__ __forceinline__ double rssi_deterministic(const Consts& c, float ux, float uy, float sx, float sy) {
+// log10 of a positive normal float32, evaluated in float64 and rounded once to float32.
+// Specification shared with the oracle (oracle/uavenv_oracle.c:orc_log10_f32), IEEE + - * / only:
+// x = m * 2^e with m folded into [sqrt(1/2), sqrt(2)); ln m = 2 atanh(s), s = (m-1)/(m+1), by the odd
+// series to s^17 (|s| <= 0.172 -> truncation 8e-16); result = e*log10(2) + ln(m)*log10(e).
+// Absolute error ~1e-15, i.e. the correctly rounded float32 log10 except with probability ~1e-8.
+__device__ __forceinline__ float log10_f32(float d) {
+    double x = (double)d;
+    int hi = __double2hiint(x), lo = __double2loint(x);
+    int e = ((hi >> 20) & 0x7FF) - 1023;
+    double m = __hiloint2double((hi & 0x000FFFFF) | 0x3FF00000, lo);
+    const bool fold = m > 1.4142135623730951;
+    m = fold ? m * 0.5 : m;
+    e = fold ? e + 1 : e;
+    double s = (m - 1.0) / (m + 1.0);
+    double s2 = s * s;
+    double p = 1.0 / 17;
+    p = p * s2 + 1.0 / 15;
+    p = p * s2 + 1.0 / 13;
+    p = p * s2 + 1.0 / 11;
+    p = p * s2 + 1.0 / 9;
+    p = p * s2 + 1.0 / 7;
+    p = p * s2 + 1.0 / 5;
+    p = p * s2 + 1.0 / 3;
+    double t = 2.0 * s;
+    double ln_m = t + t * (s2 * p);
+    double r = (double)e * 0.30102999566398120 + ln_m * 0.43429448190325182;
+    return (float)r;
+}
+
+__device__ __forceinline__ double rssi_deterministic(CRef c, float ux, float uy, float sx, float sy) {
     float dx = (ux - sx) * 10.0f;
     float dy = (uy - sy) * 10.0f;
     float ground = sqrt_rn(dx * dx + dy * dy);
     float d = sqrt_rn(ground * ground + c.alt2);
-#ifdef UAV_ABL_LOG10       // timing-only ablation build
-    float l10 = __log10f(d);
-#else
-    float l10 = (float)log10((double)d);
-#endif
+    float l10 = log10_f32(d);
     double path_loss;
     if ((double)d < c.d_break) {
         float t = 20.0f * l10;
@@ -167,7 +218,7 @@ __device__ __forceinline__ double rssi_deterministic(const Consts& c, float ux, 
 }
 
 // iot_sensors.py:223-259 update_spreading_factor (EMA-ADR), state in (avg, flags)
-__device__ __forceinline__ void adr_update(const Consts& c, double cur, double& avg, uint32_t& flags) {
+__device__ __forceinline__ void adr_update(CRef c, double cur, double& avg, uint32_t& flags) {
     double nv = cur;
     if ((flags & kAvgValid) && c.use_ema) nv = (c.lambda * cur) + (c.one_minus_lambda * avg);
     avg = nv;
@@ -180,25 +231,39 @@ __device__ __forceinline__ void adr_update(const Consts& c, double cur, double& 
 }
 
 // uav_env.py:376-384 _calculate_urgency
-__device__ __forceinline__ double calc_urgency(const Consts& c, double b, double gen, double lost) {
+__device__ __forceinline__ double calc_urgency(CRef c, double b, double gen, double lost) {
     double util = b / c.bmax;
     double loss_rate = gen > 0 ? lost / gen : 0.0;
     double u = util * (1.0 + loss_rate * 10.0);
     return u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
 }
 
-// When the lane group is the whole wavefront (G = 64) the environment record is wave-uniform: moving it to
-// SGPRs frees ~32 VGPRs and lets the compiler run the per-environment integer work on the scalar ALU.
-template <int G> __device__ __forceinline__ UavEnvRecord load_record(const UavEnvRecord* rec, size_t env) {
-    UavEnvRecord r = rec[env];
-    if (G == 64) {
-        union { UavEnvRecord r; int w[32]; } u;
-        u.r = r;
-#pragma unroll
-        for (int i = 0; i < 32; i++) u.w[i] = __builtin_amdgcn_readfirstlane(u.w[i]);
-        r = u.r;
-    }
-    return r;
+// The per-environment values the step needs from its first instruction on.  When the lane group is the
+// whole wavefront (G = 64) they are wave-uniform and are moved to SGPRs (v_readfirstlane), which frees
+// VGPRs and lets the compiler run the per-environment integer work (the action's Philox call, step
+// counters) on the scalar ALU.  The remaining ("cold") fields of the 128-byte record are only read and
+// written in the epilogue, when the per-sensor temporaries are dead.
+struct Env {
+    double battery;
+    float ux, uy;
+    int32_t step;
+    uint32_t episode, env_index;
+    int32_t n, gw, gh;
+};
+template <int G> __device__ __forceinline__ int uni(int v) { return G == 64 ? __builtin_amdgcn_readfirstlane(v) : v; }
+template <int G> __device__ __forceinline__ Env load_env(const UavEnvRecord* rp) {
+    Env e;
+    double b = rp->battery;
+    e.battery = __hiloint2double(uni<G>(__double2hiint(b)), uni<G>(__double2loint(b)));
+    e.ux = __int_as_float(uni<G>(__float_as_int(rp->uav_x)));
+    e.uy = __int_as_float(uni<G>(__float_as_int(rp->uav_y)));
+    e.step = uni<G>(rp->current_step);
+    e.episode = (uint32_t)uni<G>((int)rp->episode);
+    e.env_index = (uint32_t)uni<G>((int)rp->env_index);
+    e.n = uni<G>(rp->num_sensors);
+    e.gw = uni<G>(rp->grid_w);
+    e.gh = uni<G>(rp->grid_h);
+    return e;
 }
 
 // per-lane sensor registers
@@ -208,15 +273,23 @@ struct Sensor {
     uint32_t flags;
 };
 
-template <int G> __device__ __forceinline__ void load_sensor(const Ptrs& p, size_t idx, Sensor& s) {
-    s.sx = p.pos_x[idx]; s.sy = p.pos_y[idx];
-    s.b = p.buffer[idx]; s.gen = p.gen[idx]; s.tx = p.tx[idx]; s.lost = p.lost[idx]; s.avg = p.avg[idx];
-    s.flags = p.flags[idx];
+// SoA arrays inside the single state allocation (uavenv_internal.h): array base = sensor_base + off * S.
+template <typename T> __device__ __forceinline__ T* sensor_array(const Ptrs& p, uint64_t off) {
+    return reinterpret_cast<T*>(p.sensor_base + off * p.lanes);
 }
-template <int G> __device__ __forceinline__ void store_sensor(const Ptrs& p, size_t idx, const Sensor& s, bool with_pos) {
-    if (with_pos) { p.pos_x[idx] = s.sx; p.pos_y[idx] = s.sy; }
-    p.buffer[idx] = s.b; p.gen[idx] = s.gen; p.tx[idx] = s.tx; p.lost[idx] = s.lost; p.avg[idx] = s.avg;
-    p.flags[idx] = s.flags;
+template <int G> __device__ __forceinline__ void load_sensor(const Ptrs& p, uint32_t idx, Sensor& s) {
+    s.sx = sensor_array<float>(p, kOffPosX)[idx]; s.sy = sensor_array<float>(p, kOffPosY)[idx];
+    s.b = sensor_array<double>(p, kOffBuffer)[idx]; s.gen = sensor_array<double>(p, kOffGen)[idx];
+    s.tx = sensor_array<double>(p, kOffTx)[idx]; s.lost = sensor_array<double>(p, kOffLost)[idx];
+    s.avg = sensor_array<double>(p, kOffAvg)[idx];
+    s.flags = sensor_array<uint32_t>(p, kOffFlags)[idx];
+}
+template <int G> __device__ __forceinline__ void store_sensor(const Ptrs& p, uint32_t idx, const Sensor& s, bool with_pos) {
+    if (with_pos) { sensor_array<float>(p, kOffPosX)[idx] = s.sx; sensor_array<float>(p, kOffPosY)[idx] = s.sy; }
+    sensor_array<double>(p, kOffBuffer)[idx] = s.b; sensor_array<double>(p, kOffGen)[idx] = s.gen;
+    sensor_array<double>(p, kOffTx)[idx] = s.tx; sensor_array<double>(p, kOffLost)[idx] = s.lost;
+    sensor_array<double>(p, kOffAvg)[idx] = s.avg;
+    sensor_array<uint32_t>(p, kOffFlags)[idx] = s.flags;
 }
 
 // dqn.py:406-412 distance to the nearest sensor that still has data (float32 norm), 0 if none
@@ -250,12 +323,12 @@ template <int G> __device__ __forceinline__ double jains_index(const Sensor& s, 
 // out as contiguous dwords.  `enable` masks whole groups (a wave may hold groups that do not
 // rebuild); `dst` may be nullptr (row computed for its side effects, not stored).
 template <int G>
-__device__ __forceinline__ void observe(const Consts& c, Sensor& s, const UavEnvRecord& r, bool act, bool enable,
+__device__ __forceinline__ void observe(CRef c, Sensor& s, int n, int gw, int gh, float uxf, float uyf,
+                                        double battery, bool act, bool enable,
                                         double det, float zD, float zE, float* dst, float* lds_row) {
     const int gl = group_lane<G>();
-    const int n = r.num_sensors;
-    double W = (double)r.grid_w, H = (double)r.grid_h;
-    double ux = (double)r.uav_x, uy = (double)r.uav_y;
+    double W = (double)gw, H = (double)gh;
+    double ux = (double)uxf, uy = (double)uyf;
     float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f, f4 = 0.f;
     if (enable && act) {
         double urgency = calc_urgency(c, s.b, s.gen, s.lost);                 // :652 (before the ADR update)
@@ -275,7 +348,7 @@ __device__ __forceinline__ void observe(const Consts& c, Sensor& s, const UavEnv
         if (gl == 0) {
             lds_row[0] = (float)(ux / W);
             lds_row[1] = (float)(uy / H);
-            lds_row[2] = (float)(r.battery / c.maxb);
+            lds_row[2] = (float)(battery / c.maxb);
         }
         if (act) {
             float* q = lds_row + 3 + c.fps * gl;
@@ -296,13 +369,16 @@ __device__ __forceinline__ void observe(const Consts& c, Sensor& s, const UavEnv
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Noise for one step of one lane: Philox, or the injected tape (parity testing)
-struct StepNoise { float zA, zB, u, zC, zD, zE; };
+// Noise for one step of one lane: Philox, or the injected tape (parity testing).  zC (the range check of
+// collect_data) is only needed by Capture-Effect winners, so its Box-Muller is deferred: the two Philox
+// words are kept and converted on demand (finish_zc).
+struct StepNoise { float zA, zB, u, zC, zD, zE; uint32_t c2, c3; bool zc_ready; };
 
 template <int G>
-__device__ __forceinline__ void draw_step_noise(const Consts& c, const Ptrs& p, const UavEnvRecord& r, size_t env,
-                                                bool in_batch, uint32_t step, bool need_collect, StepNoise& z) {
+__device__ __forceinline__ void draw_step_noise(CRef c, const Ptrs& p, uint32_t env_index, uint32_t episode,
+                                                size_t env, bool in_batch, uint32_t step, bool need_collect, StepNoise& z) {
     const int gl = group_lane<G>();
+    z.c2 = z.c3 = 0u; z.zc_ready = true;
     if (p.step_tape != nullptr) {                      // kernel-uniform
         z.zA = z.zB = z.zC = z.zD = z.zE = 0.f; z.u = 1.f;
         if (in_batch) {                                // the tape has no rows for the padding environments
@@ -311,23 +387,25 @@ __device__ __forceinline__ void draw_step_noise(const Consts& c, const Ptrs& p, 
         }
         return;
     }
-    Words4 w = noise_words(c.seed, r.env_index, r.episode, step, (uint32_t)gl, 0);
+    Words4 w = noise_words(c.seed, env_index, episode, step, (uint32_t)gl, 0);
     normal_pair(w.w0, w.w1, z.zD, z.zE);
     z.u = u24(w.w2);
     z.zA = z.zB = z.zC = 0.f;
     if (need_collect) {                       // wave-uniform
-        Words4 v = noise_words(c.seed, r.env_index, r.episode, step, (uint32_t)gl, 1);
-        float spare;
+        Words4 v = noise_words(c.seed, env_index, episode, step, (uint32_t)gl, 1);
         normal_pair(v.w0, v.w1, z.zA, z.zB);
-        normal_pair(v.w2, v.w3, z.zC, spare);
+        z.c2 = v.w2; z.c3 = v.w3; z.zc_ready = false;
     }
+}
+__device__ __forceinline__ void finish_zc(StepNoise& z) {   // call under wave-uniform control flow
+    if (!z.zc_ready) { float spare; normal_pair(z.c2, z.c3, z.zC, spare); z.zc_ready = true; }
 }
 
 // uav_env.py:400-427 reset (+ iot_sensors.py:305-321, uav.py:241-258; DomainRandEnv.reset
 // dqn.py:301-373 under the flags) for the groups with `rs` set.  Leaves the new episode's sensor
 // registers in `s`, the record in `r`, and returns (zD, zE) of the reset observation.
 template <int G>
-__device__ __forceinline__ void reset_group(const Consts& c, const Ptrs& p, Sensor& s, UavEnvRecord& r, size_t env,
+__device__ __forceinline__ void reset_group(CRef c, const Ptrs& p, Sensor& s, UavEnvRecord& r, size_t env,
                                             bool in_batch, bool rs, bool draw_layout, float& zD, float& zE) {
     const int gl = group_lane<G>();
     if (!rs) return;                                   // group-uniform; no cross-lane ops skipped below
@@ -374,7 +452,7 @@ __device__ __forceinline__ void reset_group(const Consts& c, const Ptrs& p, Sens
 // dqn.py:375-403 _sample_far_start: rejection-sample a start >= min_start_dist from every sensor,
 // falling back to the furthest candidate.  Candidates from Philox call 4 (lane field = try).
 template <int G>
-__device__ __forceinline__ void far_start(const Consts& c, const Sensor& s, UavEnvRecord& r, bool act, bool rs) {
+__device__ __forceinline__ void far_start(CRef c, const Sensor& s, UavEnvRecord& r, bool act, bool rs) {
     double W = (double)r.grid_w, H = (double)r.grid_h;
     float best_x = r.start_x, best_y = r.start_y, best_d = -1.0f;
     bool searching = rs;
@@ -398,18 +476,20 @@ __device__ __forceinline__ void far_start(const Consts& c, const Sensor& s, UavE
 // init kernel: records + (optionally) Philox sensor layouts, no episode started
 // ---------------------------------------------------------------------------------------------
 template <int G>
-__global__ __launch_bounds__(kBlockThreads) void uav_init_kernel(Consts c, Ptrs p, uint32_t env_index_base,
+__global__ __launch_bounds__(kBlockThreads) void uav_init_kernel(const Consts* cptr, Ptrs p, uint32_t env_index_base,
                                                                  int32_t grid_w, int32_t grid_h, int32_t n,
                                                                  float start_x, float start_y) {
+    UAV_CONSTS(cptr);
     const int gl = group_lane<G>();
-    const size_t env = (size_t)blockIdx.x * (kBlockThreads / G) + threadIdx.x / G;
-    const size_t idx = env * G + gl;
-    uint32_t gidx = env_index_base + (uint32_t)env;
+    const uint32_t env = blockIdx.x * (kBlockThreads / G) + threadIdx.x / G;
+    const uint32_t idx = env * G + gl;
+    uint32_t gidx = env_index_base + env;
     Words4 w = noise_words(c.seed, gidx, 0xFFFFFFFFu, 0u, (uint32_t)gl, 2);
-    p.pos_x[idx] = u24(w.w1) * (float)grid_w;
-    p.pos_y[idx] = u24(w.w2) * (float)grid_h;
-    p.buffer[idx] = 0.0; p.gen[idx] = 0.0; p.tx[idx] = 0.0; p.lost[idx] = 0.0; p.avg[idx] = 0.0;
-    p.flags[idx] = 12u;
+    Sensor s;
+    s.sx = u24(w.w1) * (float)grid_w;
+    s.sy = u24(w.w2) * (float)grid_h;
+    s.b = 0.0; s.gen = 0.0; s.tx = 0.0; s.lost = 0.0; s.avg = 0.0; s.flags = 12u;
+    store_sensor<G>(p, idx, s, true);
     if (gl == 0) {
         UavEnvRecord r;
         r.battery = c.maxb; r.total_reward = 0.0; r.total_data_collected = 0.0; r.last_step_bytes = 0.0;
@@ -431,17 +511,18 @@ __global__ __launch_bounds__(kBlockThreads) void uav_init_kernel(Consts c, Ptrs 
 // reset kernel
 // ---------------------------------------------------------------------------------------------
 template <int G>
-__global__ __launch_bounds__(kBlockThreads) void uav_reset_kernel(Consts c, Ptrs p, ResetArgs a) {
+__global__ __launch_bounds__(kBlockThreads) void uav_reset_kernel(const Consts* cptr, Ptrs p, ResetArgs a) {
+    UAV_CONSTS(cptr);
     extern __shared__ float lds[];
     const int gl = group_lane<G>();
-    const size_t env = (size_t)blockIdx.x * (kBlockThreads / G) + threadIdx.x / G;
-    const size_t idx = env * G + gl;
+    const uint32_t env = blockIdx.x * (kBlockThreads / G) + threadIdx.x / G;
+    const uint32_t idx = env * G + gl;
     float* lds_row = lds + (threadIdx.x / G) * c.obs_dim;
 
-    UavEnvRecord r = load_record<G>(p.rec, env);
+    UavEnvRecord r = p.rec[env];
     Sensor s;
     load_sensor<G>(p, idx, s);
-    const bool in_batch = env < (size_t)a.num_envs;
+    const bool in_batch = env < (uint32_t)a.num_envs;
     bool rs = true;
     if (a.mask != nullptr) rs = in_batch && a.mask[env] != 0;
     const bool act = gl < r.num_sensors;
@@ -453,7 +534,7 @@ __global__ __launch_bounds__(kBlockThreads) void uav_reset_kernel(Consts c, Ptrs
     if (rs) { r.uav_x = r.start_x; r.uav_y = r.start_y; }                         // uav.py:256, dqn.py:364-365
     double det = rssi_deterministic(c, r.uav_x, r.uav_y, s.sx, s.sy);
     float* dst = (in_batch && a.obs != nullptr) ? a.obs + env * (size_t)c.obs_dim : nullptr;
-    observe<G>(c, s, r, act, rs, det, zD, zE, dst, lds_row);                       // uav_env.py:427
+    observe<G>(c, s, r.num_sensors, r.grid_w, r.grid_h, r.uav_x, r.uav_y, r.battery, act, rs, det, zD, zE, dst, lds_row);   // uav_env.py:427
     if (c.flags & UAVENV_FLAG_PROX_SHAPING) {
         double d0 = dist_nearest_with_data<G>(s, act, r.uav_x, r.uav_y);           // dqn.py:368
         if (rs) r.prev_dist_nearest = d0;
@@ -468,43 +549,46 @@ __global__ __launch_bounds__(kBlockThreads) void uav_reset_kernel(Consts c, Ptrs
 // step kernel: the hot path
 // ---------------------------------------------------------------------------------------------
 template <int G>
-__global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_kernel(Consts c, Ptrs p, StepArgs a) {
+__global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_kernel(const Consts* cptr, Ptrs p, StepArgs a) {
+    UAV_CONSTS(cptr);
     extern __shared__ float lds[];
 #ifdef UAVENV_STAMPS
     const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const int gl = group_lane<G>();
-    const size_t env = (size_t)blockIdx.x * (kBlockThreads / G) + threadIdx.x / G;
-    const size_t idx = env * G + gl;
+    const uint32_t env = blockIdx.x * (kBlockThreads / G) + uni<G>((int)(threadIdx.x / G));
+    const uint32_t idx = env * G + gl;
     float* lds_row = lds + (threadIdx.x / G) * c.obs_dim;
-    const bool in_batch = env < (size_t)a.num_envs;
+    const bool in_batch = env < (uint32_t)a.num_envs;
 
-    UavEnvRecord r = load_record<G>(p.rec, env);
+    const UavEnvRecord* rp = p.rec + env;
+    Env e = load_env<G>(rp);
     Sensor s;
     load_sensor<G>(p, idx, s);
-    const int n = r.num_sensors;
+    const int n = e.n;
     const bool act = gl < n;
 
     // ---- action -----------------------------------------------------------------------------
-    const uint32_t step = (uint32_t)(r.current_step + 1);
+    const uint32_t step = (uint32_t)(e.step + 1);
     int action;
-    if (a.actions != nullptr) action = in_batch ? a.actions[env] : 0;
+    if (a.actions != nullptr) action = uni<G>(in_batch ? a.actions[env] : 0);
     else {                                                       // uniform-random policy (Philox call 3)
-        Words4 w = noise_words(c.seed, r.env_index, r.episode, step, 0u, 3);
+        Words4 w = noise_words(c.seed, e.env_index, e.episode, step, 0u, 3);
         action = (int)(((uint64_t)w.w0 * 5u) >> 32);
         if (a.actions_out != nullptr && in_batch && gl == 0) a.actions_out[env] = action;
     }
     const bool is_c = action == 4;
     const bool is_m = (action >= 0) & (action <= 3);
-    r.status |= (!is_c & !is_m) ? 1u : 0u;                      // uav_env.py:468 ValueError (after ageing)
+    const uint32_t status_bits = (!is_c & !is_m) ? 1u : 0u;     // uav_env.py:468 ValueError (after ageing)
 
     // ---- uav_env.py:439-447: step counter, edge-cell bookkeeping on the PRE-move position --------
-    r.current_step += 1;
+    e.step += 1;
+    int edge_inc;
     {
-        double W = (double)r.grid_w, H = (double)r.grid_h, ux = (double)r.uav_x, uy = (double)r.uav_y;
+        double W = (double)e.gw, H = (double)e.gh, ux = (double)e.ux, uy = (double)e.uy;
         const double eps = 1e-6;
         const bool edge = (ux <= eps) | (uy <= eps) | (ux >= W - 1 - eps) | (uy >= H - 1 - eps);
-        r.edge_steps += edge ? 1 : 0;
+        edge_inc = edge ? 1 : 0;
     }
     // ---- :450-459 age all sensors (iot_sensors.py:114-125), data-loss delta ------------------------
     const double step_duration = is_c ? c.coll_dur : 1.0;
@@ -521,22 +605,23 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_ker
     }
     const double step_data_loss = gsum<G>(loss);
 
-    const double prev_dist = r.prev_dist_nearest;               // dqn.py:417
     double reward = 0.0;
+    double bytes_step = 0.0;          // uav_env.py:607 last_step_bytes_collected
+    int captures = 0, collisions = 0, bh_inc = 0;
 
     // ---- :494-516 move (uav.py:127-185, reward_function.py:69-79); scalar per group ---------------
     // Written branch-free (bitwise &, selects) on purpose: ROCm 7.2's gfx950 backend mis-compiled the
     // natural `ok = a && b && c && d; if (ok) {..} else {..}` form here (the e_move / r_move selects were
     // sunk into the `0 <= nx` block only; caught by the parity tests).
     {
-        const double battery_before = r.battery;
+        const double battery_before = e.battery;
         const float dxm = action == 2 ? -1.0f : (action == 3 ? 1.0f : 0.0f);
         const float dym = action == 0 ? 1.0f : (action == 1 ? -1.0f : 0.0f);
-        const float nx = r.uav_x + dxm, ny = r.uav_y + dym;
-        const bool ok = (0.0f <= nx) & (nx < (float)r.grid_w) & (0.0f <= ny) & (ny < (float)r.grid_h);
+        const float nx = e.ux + dxm, ny = e.uy + dym;
+        const bool ok = (0.0f <= nx) & (nx < (float)e.gw) & (0.0f <= ny) & (ny < (float)e.gh);
         const bool mv = is_m & ok;
-        r.uav_x = mv ? nx : r.uav_x;
-        r.uav_y = mv ? ny : r.uav_y;
+        e.ux = mv ? nx : e.ux;
+        e.uy = mv ? ny : e.uy;
         const double drain = ok ? c.e_move : c.e_coll;
         const double battery_after = battery_before - drain;
         const double battery_used = battery_before - battery_after;
@@ -544,41 +629,56 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_ker
         rw += ok ? c.r_move : c.p_boundary;
         rw += c.p_battery * battery_used;
         rw += c.p_loss * step_data_loss;
-        r.battery = is_m ? battery_after : r.battery;
-        r.boundary_hits += (is_m & !ok) ? 1 : 0;
-        r.last_step_bytes = is_m ? 0.0 : r.last_step_bytes;
+        e.battery = is_m ? battery_after : e.battery;
+        bh_inc = (is_m & !ok) ? 1 : 0;
         reward = is_m ? rw : 0.0;
     }
 
     // One deterministic path-loss evaluation per sensor and step: a collect step does not move the
     // UAV, so the five RSSI samples of a step (zA,zB,zC at the pre-action position, zD,zE at the
     // post-action position) all share it.
-    const double det = rssi_deterministic(c, r.uav_x, r.uav_y, s.sx, s.sy);
+    const double det = rssi_deterministic(c, e.ux, e.uy, s.sx, s.sy);
 
     const bool any_c = __any(is_c) != 0;
     StepNoise z;
-    draw_step_noise<G>(c, p, r, env, in_batch, step, any_c, z);
+    draw_step_noise<G>(c, p, e.env_index, e.episode, env, in_batch, step, any_c, z);
 
     // ---- :518-632 collect with Capture-Effect collision handling ---------------------------------
     if (any_c) {
-        const bool actc = act && is_c;
-        float urg_before = 0.0f;
-        if (actc && c.rate > 0) urg_before = (float)(s.b / c.rate);            // P0 :526 (float32 AoI)
-        if (is_c) r.battery -= c.e_hover;                                      // P1 :529
+        const bool actc = act & is_c;
+        // P0 :526 float32 AoI urgency  b / rate
+        const float urg_before = (actc & (c.rate > 0)) ? (float)(s.b / c.rate) : 0.0f;
+        e.battery = is_c ? e.battery - c.e_hover : e.battery;                  // P1 :529
         // P2 :535-551
-        const bool has = actc && s.b > 0;
+        const bool has = actc & (s.b > 0);
         double cur = 0.0;
-        if (has) {
-            cur = det + c.sigma * (double)z.zA;
-            adr_update(c, cur, s.avg, s.flags);                                 // :539
+        {
+            const double cand = det + c.sigma * (double)z.zA;
+            double avg2 = s.avg; uint32_t fl2 = s.flags;
+            adr_update(c, cand, avg2, fl2);                                     // :539
+            cur = has ? cand : 0.0;
+            s.avg = has ? avg2 : s.avg;
+            s.flags = has ? fl2 : s.flags;
         }
         const uint32_t sf = s.flags & kSfMask;
-        bool attempt = false;
-        if (has) {
-            double rssi = det + c.sigma * (double)z.zB;                         // :543 get_success_probability
-            double p_link = 0.0;
-            if (!(rssi < c.thr)) p_link = 1.0 / (1.0 + exp(-((rssi - c.noise_floor) - sf_required_snr(sf))));
-            attempt = (p_link * c.p_cycle) > (double)z.u;                      // :549
+        bool attempt;
+        {
+            // :543 get_success_probability(advanced): p = 0 below the threshold, else the SNR sigmoid.
+            // The sigmoid is within 2.1e-9 of 1 for x > 20, so `p * p_cycle > u` is decided without the
+            // exponential unless u falls into that 2e-9-wide band (then the exact expression is used).
+            const double rssi = det + c.sigma * (double)z.zB;
+            const double x = (rssi - c.noise_floor) - sf_required_snr(sf);
+            const double u = (double)z.u;
+            const bool in_rng = !(rssi < c.thr);
+            const bool sure_yes = (x > 20.0) & ((c.p_cycle * (1.0 - 2.2e-9)) > u);
+            const bool sure_no = !(c.p_cycle > u);
+            const bool need_exp = has & in_rng & !sure_yes & !sure_no;
+            bool att = sure_yes;
+            if (__any(need_exp)) {
+                const double p_link = 1.0 / (1.0 + exp(-x));
+                att = need_exp ? ((p_link * c.p_cycle) > u) : att;
+            }
+            attempt = has & in_rng & att;                                       // :549
         }
         // P3 :554-572: per SF class, sole attempter wins; else top wins iff > second + 6 dB.
         // Each attempter scans the (few) other attempters of its group.
@@ -600,87 +700,88 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_ker
         const bool contested = attempt & (others > 0);
         const bool winner = attempt & ((others == 0) | (!beaten & (cur > (omax + c.cap_thr))));
         const int collision_count = __popcll(gballot<G>(contested)) - __popcll(gballot<G>(contested & !lower_same));
-        const int captures = __popcll(gballot<G>(winner & contested));
-        // P4 :575-594 + iot_sensors.py:127-145 collect_data
+        const int capt = __popcll(gballot<G>(winner & contested));
+        // P4 :575-594 + iot_sensors.py:127-145 collect_data (range check with a fresh sample zC: winners only)
         double bytes = 0.0;
         bool got = false;
-        if (winner) {
-            double rssi = det + c.sigma * (double)z.zC;
-            bool in_range = !(rssi < c.thr);
-            if (in_range && s.b > 0) {
-                double max_collectible = sf_data_rate(sf) * c.coll_dur;
-                bytes = s.b < max_collectible ? s.b : max_collectible;
-                s.b -= bytes;
-                s.tx += bytes;
-                if (bytes > 0) { s.flags |= kDataCollected; got = true; }
-            }
+        if (__any(winner)) {
+            finish_zc(z);
+            const double rssi = det + c.sigma * (double)z.zC;
+            const bool take = winner & !(rssi < c.thr) & (s.b > 0);
+            const double max_collectible = sf_data_rate(sf) * c.coll_dur;
+            const double by = s.b < max_collectible ? s.b : max_collectible;
+            bytes = take ? by : 0.0;
+            s.b = take ? s.b - by : s.b;
+            s.tx = take ? s.tx + by : s.tx;
+            got = take & (by > 0);
+            s.flags |= got ? kDataCollected : 0u;
         }
         const double total_bytes = gsum<G>(bytes);
-        const bool any_new = gany<G>(got && !(s.flags & kVisited));
-        if (got) s.flags |= kVisited;
+        const bool any_new = gany<G>(got & !(s.flags & kVisited));
+        s.flags |= got ? kVisited : 0u;
         const int nw = __popcll(gballot<G>(winner));
-        const bool attempted_empty = gany<G>(actc && s.b <= 0);                 // :596
-        const bool all_collected = !gany<G>(actc && s.b > 0);                   // :604
-        // P5 :599-602 (float32)
+        const bool attempted_empty = gany<G>(actc & (s.b <= 0));                // :596
+        const bool all_collected = !gany<G>(actc & (s.b > 0));                  // :604
+        // P5 :599-602 (float32); only drained sensors changed their AoI urgency
         float diff = 0.0f;
-        if (actc) {
-            float urg_after = c.rate > 0 ? (float)(s.b / c.rate) : 0.0f;
-            float d = urg_before - urg_after;
-            diff = d > 0.0f ? d : 0.0f;
+        if (__any(got)) {
+            const float urg_after = (actc & (c.rate > 0)) ? (float)(s.b / c.rate) : 0.0f;
+            const float d = urg_before - urg_after;
+            diff = (got & (d > 0.0f)) ? d : 0.0f;
         }
         const double urgency_reduced = (double)np_sum_f32<G>(diff, n);
         // P6 :607-630
         double mean_urgency = 0.0;
-        {
-            double ui = winner ? calc_urgency(c, s.b, s.gen, s.lost) : 0.0;
-            double su = gsum<G>(ui);
-            if (nw > 0) mean_urgency = su / nw;
+        if (__any(winner)) {
+            const double ui = winner ? calc_urgency(c, s.b, s.gen, s.lost) : 0.0;
+            const double su = gsum<G>(ui);
+            mean_urgency = nw > 0 ? su / nw : 0.0;
         }
         // reward_function.py:46-57 variance "starvation" penalty (np.var: two-pass, ddof 0)
         double starvation = 0.0;
         {
-            double mx = gmax<G>(actc ? s.b : -__builtin_inf());
-            bool use = n > 1 && mx != 0;
-            double nb = (actc && use) ? s.b / mx : 0.0;
-            double mean = gsum<G>(nb) / n;
-            double dv = (actc && use) ? (nb - mean) * (nb - mean) : 0.0;
-            double var = gsum<G>(dv) / n;
-            if (use) starvation = c.p_starvation * var;
+            const double mx = gmax<G>(actc ? s.b : -__builtin_inf());
+            const bool use = (n > 1) & (mx != 0);
+            const double nb = (actc & use) ? s.b / mx : 0.0;
+            const double mean = gsum<G>(nb) / n;
+            const double dv = (actc & use) ? (nb - mean) * (nb - mean) : 0.0;
+            const double var = gsum<G>(dv) / n;
+            starvation = use ? c.p_starvation * var : 0.0;
         }
-        if (is_c) {
-            r.total_data_collected += total_bytes;
-            r.last_step_bytes = total_bytes;
-            r.capture_triggers += captures;
-            r.collisions_total += collision_count;
+        {
             double rw = c.p_step + c.p_hover;                                   // reward_function.py:97
-            if (total_bytes > 0) {
-                rw += c.r_byte * total_bytes * mean_urgency;
-                if (any_new) rw += c.r_new;
+            {
+                const double r1 = rw + c.r_byte * total_bytes * mean_urgency;  // :100-103
+                const double r2 = any_new ? r1 + c.r_new : r1;
+                rw = (total_bytes > 0) ? r2 : rw;
             }
-            if (urgency_reduced > 0) rw += c.r_urg * urgency_reduced;
-            if (attempted_empty && total_bytes == 0) rw += c.p_revisit;
+            rw = (urgency_reduced > 0) ? rw + c.r_urg * urgency_reduced : rw;
+            rw = (attempted_empty & (total_bytes == 0)) ? rw + c.p_revisit : rw;
             rw += c.p_battery * c.used_hover;
-            if (collision_count > 0) rw += c.p_collision * collision_count;
-            if (step_data_loss > 0) rw += c.p_loss * step_data_loss;
+            rw = (collision_count > 0) ? rw + c.p_collision * collision_count : rw;
+            rw = (step_data_loss > 0) ? rw + c.p_loss * step_data_loss : rw;
             rw += starvation;
-            if (all_collected) rw += c.r_done;
-            reward = rw;
+            rw = all_collected ? rw + c.r_done : rw;
+            reward = is_c ? rw : reward;
+            bytes_step = is_c ? total_bytes : 0.0;
+            captures = is_c ? capt : 0;
+            collisions = is_c ? collision_count : 0;
         }
     }
 
     // ---- :471-487 truncation + terminal penalties (reward_function.py:59-67) -------------------
-    const bool truncated = !(r.battery > c.alive_level) | (r.current_step >= c.max_steps);   // uav.py:224, uav_env.py:477
-    const int visited_cnt = __popcll(gballot<G>(act && (s.flags & kVisited)));
-    {
+    const bool truncated = !(e.battery > c.alive_level) | (e.step >= c.max_steps);   // uav.py:224, uav_env.py:477
+    const int visited_cnt = __popcll(gballot<G>(act & ((s.flags & kVisited) != 0u)));
+    if (__any(truncated)) {
         const bool starved = act & (s.gen > 0) & ((s.tx / s.gen) < c.cr_thr);
-        int starved_cnt = __popcll(gballot<G>(starved));
-        if (truncated) {
-            int unvisited = n - visited_cnt;
-            if (unvisited > 0) reward += c.p_unvisited * unvisited;
-            reward += c.p_starved * starved_cnt;
-        }
+        const int starved_cnt = __popcll(gballot<G>(starved));
+        const int unvisited = n - visited_cnt;
+        double pen = (unvisited > 0) ? c.p_unvisited * unvisited : 0.0;
+        double rt = reward + pen;
+        rt += c.p_starved * starved_cnt;
+        reward = truncated ? rt : reward;
     }
-    r.total_reward += reward;
+    const double reward_unshaped = reward;                                        // :487 total_reward += reward
 
     // ---- observation of the stepped state (side effect: ADR EMA) -------------------------------
     const bool auto_reset = (c.flags & UAVENV_FLAG_AUTO_RESET) != 0;
@@ -691,16 +792,32 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_ker
             if (do_reset) dst = a.term_obs ? a.term_obs + env * (size_t)c.obs_dim : nullptr;
             else dst = a.obs ? a.obs + env * (size_t)c.obs_dim : nullptr;
         }
-        observe<G>(c, s, r, act, true, det, z.zD, z.zE, dst, lds_row);          // :488
+        observe<G>(c, s, n, e.gw, e.gh, e.ux, e.uy, e.battery, act, true, det, z.zD, z.zE, dst, lds_row);   // :488
     }
+
+    // ---- epilogue: the cold part of the record (read late on purpose: see struct Env) -----------------
+    asm volatile("" ::: "memory");
+    UavEnvRecord r = p.rec[env];
+    r.battery = e.battery; r.uav_x = e.ux; r.uav_y = e.uy; r.current_step = e.step;
+    r.episode = e.episode; r.env_index = e.env_index; r.num_sensors = e.n; r.grid_w = e.gw; r.grid_h = e.gh;
+    r.status |= status_bits;
+    r.edge_steps += edge_inc;
+    r.boundary_hits += bh_inc;
+    r.total_reward += reward_unshaped;
+    r.total_data_collected += bytes_step;
+    r.last_step_bytes = (is_m | is_c) ? bytes_step : r.last_step_bytes;           // :463, :607
+    r.capture_triggers += captures;
+    r.collisions_total += collisions;
 
     // ---- DomainRandEnv.step extras (dqn.py:415-444) ---------------------------------------------
     if (c.flags & UAVENV_FLAG_PROX_SHAPING) {
-        double curr = dist_nearest_with_data<G>(s, act, r.uav_x, r.uav_y);
-        if (prev_dist > 0) reward += c.prox_eta * (prev_dist - curr);
+        const double prev_dist = r.prev_dist_nearest;                             // dqn.py:417
+        double curr = dist_nearest_with_data<G>(s, act, e.ux, e.uy);
+        reward = (prev_dist > 0) ? reward + c.prox_eta * (prev_dist - curr) : reward;
         r.prev_dist_nearest = curr;
     }
-    if (r.first_full_coverage_step < 0 && visited_cnt == n) r.first_full_coverage_step = r.current_step;
+    r.first_full_coverage_step = ((r.first_full_coverage_step < 0) & (visited_cnt == n)) ? e.step
+                                                                                       : r.first_full_coverage_step;
     if (c.flags & UAVENV_FLAG_JAIN_BONUS) reward += c.jain_weight * (jains_index<G>(s, act, nullptr) - 0.5) / n;
     r.episode_return += reward;
 
@@ -736,7 +853,7 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_ker
         if (do_reset) { r.uav_x = r.start_x; r.uav_y = r.start_y; }
         double det0 = rssi_deterministic(c, r.uav_x, r.uav_y, s.sx, s.sy);
         float* dst = (in_batch && a.obs) ? a.obs + env * (size_t)c.obs_dim : nullptr;
-        observe<G>(c, s, r, act, do_reset, det0, zD, zE, dst, lds_row);
+        observe<G>(c, s, r.num_sensors, r.grid_w, r.grid_h, r.uav_x, r.uav_y, r.battery, act, do_reset, det0, zD, zE, dst, lds_row);
         if (c.flags & UAVENV_FLAG_PROX_SHAPING) {
             double d0 = dist_nearest_with_data<G>(s, act, r.uav_x, r.uav_y);
             if (do_reset) r.prev_dist_nearest = d0;
@@ -764,16 +881,18 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_ker
 // noise dump: the tapes the NEXT step / NEXT reset would draw (parity harness for Philox mode)
 // ---------------------------------------------------------------------------------------------
 template <int G>
-__global__ __launch_bounds__(kBlockThreads) void uav_dump_noise_kernel(Consts c, Ptrs p, float* step_tape,
+__global__ __launch_bounds__(kBlockThreads) void uav_dump_noise_kernel(const Consts* cptr, Ptrs p, float* step_tape,
                                                                        float* reset_tape, int32_t num_envs) {
+    UAV_CONSTS(cptr);
     const int gl = group_lane<G>();
-    const size_t env = (size_t)blockIdx.x * (kBlockThreads / G) + threadIdx.x / G;
-    if (env >= (size_t)num_envs) return;
+    const uint32_t env = blockIdx.x * (kBlockThreads / G) + threadIdx.x / G;
+    if (env >= (uint32_t)num_envs) return;
     UavEnvRecord r = p.rec[env];
     if (step_tape) {
         Ptrs q = p; q.step_tape = nullptr;
         StepNoise z;
-        draw_step_noise<G>(c, q, r, env, true, (uint32_t)(r.current_step + 1), true, z);
+        draw_step_noise<G>(c, q, r.env_index, r.episode, env, true, (uint32_t)(r.current_step + 1), true, z);
+        finish_zc(z);
         float* t = step_tape + env * (size_t)(UAVENV_TAPE_STEP_SLOTS * G) + gl;
         t[0 * G] = z.zA; t[1 * G] = z.zB; t[2 * G] = z.u; t[3 * G] = z.zC; t[4 * G] = z.zD; t[5 * G] = z.zE;
     }
@@ -801,26 +920,26 @@ static inline size_t lds_bytes(int G, const Consts& c) { return (size_t)(kBlockT
         default: return hipErrorInvalidValue;           \
     }
 
-hipError_t launch_init(int Gw, int padded_envs, const Consts& c, const Ptrs& p, uint32_t env_index_base,
+hipError_t launch_init(int Gw, int padded_envs, const Consts& c, const Consts* dc, const Ptrs& p, uint32_t env_index_base,
                        int32_t grid_w, int32_t grid_h, int32_t n, float start_x, float start_y, hipStream_t s) {
     dim3 block(kBlockThreads), grid((unsigned)(padded_envs / (kBlockThreads / Gw)));
-    UAV_DISPATCH_G(Gw, (uav_init_kernel<G><<<grid, block, 0, s>>>(c, p, env_index_base, grid_w, grid_h, n, start_x, start_y)));
+    UAV_DISPATCH_G(Gw, (uav_init_kernel<G><<<grid, block, 0, s>>>(dc, p, env_index_base, grid_w, grid_h, n, start_x, start_y)));
     return hipGetLastError();
 }
-hipError_t launch_reset(int Gw, int padded_envs, const Consts& c, const Ptrs& p, const ResetArgs& a, hipStream_t s) {
+hipError_t launch_reset(int Gw, int padded_envs, const Consts& c, const Consts* dc, const Ptrs& p, const ResetArgs& a, hipStream_t s) {
     dim3 block(kBlockThreads), grid((unsigned)(padded_envs / (kBlockThreads / Gw)));
-    UAV_DISPATCH_G(Gw, (uav_reset_kernel<G><<<grid, block, lds_bytes(Gw, c), s>>>(c, p, a)));
+    UAV_DISPATCH_G(Gw, (uav_reset_kernel<G><<<grid, block, lds_bytes(Gw, c), s>>>(dc, p, a)));
     return hipGetLastError();
 }
-hipError_t launch_step(int Gw, int padded_envs, const Consts& c, const Ptrs& p, const StepArgs& a, hipStream_t s) {
+hipError_t launch_step(int Gw, int padded_envs, const Consts& c, const Consts* dc, const Ptrs& p, const StepArgs& a, hipStream_t s) {
     dim3 block(kBlockThreads), grid((unsigned)(padded_envs / (kBlockThreads / Gw)));
-    UAV_DISPATCH_G(Gw, (uav_step_kernel<G><<<grid, block, lds_bytes(Gw, c), s>>>(c, p, a)));
+    UAV_DISPATCH_G(Gw, (uav_step_kernel<G><<<grid, block, lds_bytes(Gw, c), s>>>(dc, p, a)));
     return hipGetLastError();
 }
-hipError_t launch_dump_noise(int Gw, int padded_envs, const Consts& c, const Ptrs& p, float* step_tape,
+hipError_t launch_dump_noise(int Gw, int padded_envs, const Consts& c, const Consts* dc, const Ptrs& p, float* step_tape,
                              float* reset_tape, int32_t num_envs, hipStream_t s) {
     dim3 block(kBlockThreads), grid((unsigned)(padded_envs / (kBlockThreads / Gw)));
-    UAV_DISPATCH_G(Gw, (uav_dump_noise_kernel<G><<<grid, block, 0, s>>>(c, p, step_tape, reset_tape, num_envs)));
+    UAV_DISPATCH_G(Gw, (uav_dump_noise_kernel<G><<<grid, block, 0, s>>>(dc, p, step_tape, reset_tape, num_envs)));
     return hipGetLastError();
 }
 

@@ -100,6 +100,35 @@ static double sf_link_quality(int sf) {
 
 /* iot_sensors.py:147-189  deterministic part of calculate_rssi (everything before the shadowing
  * draw).  Distances in float32, 20*log10f(d) in float32, the rest in float64. */
+/* log10 of a positive normal float32 in float64, rounded once: the correctly rounded float32 log10
+ * except with probability ~1e-8 (absolute error ~1e-15).  A fixed IEEE + - * / sequence (no libm) so
+ * that the HIP kernel, which evaluates the same specification, agrees bit for bit:
+ *   x = m * 2^e, m folded into [sqrt(1/2), sqrt(2));  ln m = 2 atanh(s), s = (m-1)/(m+1), odd series to s^17;
+ *   result = e*log10(2) + ln(m)*log10(e).
+ * (The reference's own np.log10(float32) is a platform routine that is 1 ulp off on 47 % of inputs.) */
+float orc_log10_f32(float d) {
+    double x = (double)d;
+    uint64_t bits; memcpy(&bits, &x, 8);
+    int e = (int)((bits >> 52) & 0x7FF) - 1023;
+    uint64_t mb = (bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+    double m; memcpy(&m, &mb, 8);
+    if (m > 1.4142135623730951) { m = m * 0.5; e = e + 1; }
+    double s = (m - 1.0) / (m + 1.0);
+    double s2 = s * s;
+    double p = 1.0 / 17;
+    p = p * s2 + 1.0 / 15;
+    p = p * s2 + 1.0 / 13;
+    p = p * s2 + 1.0 / 11;
+    p = p * s2 + 1.0 / 9;
+    p = p * s2 + 1.0 / 7;
+    p = p * s2 + 1.0 / 5;
+    p = p * s2 + 1.0 / 3;
+    double t = 2.0 * s;
+    double ln_m = t + t * (s2 * p);
+    double r = (double)e * 0.30102999566398120 + ln_m * 0.43429448190325182;
+    return (float)r;
+}
+
 double orc_rssi_deterministic(const OrcConfig* c, float ux, float uy, float sx, float sy) {
     float dx = (ux - sx) * 10.0f;                         /* :161 */
     float dy = (uy - sy) * 10.0f;                         /* :162 */
@@ -108,7 +137,7 @@ double orc_rssi_deterministic(const OrcConfig* c, float ux, float uy, float sx, 
     float d = sqrtf(ground * ground + alt2);              /* :164 */
     double ht = c->sensor_height, hr = c->uav_altitude;
     double d_break = (4 * M_PI * ht * hr) / c->wavelength;    /* :174 */
-    float l10 = (float)log10((double)d);                  /* correctly rounded float32 log10 */
+    float l10 = orc_log10_f32(d);                         /* correctly rounded float32 log10 (w.p. 1 - 1e-8) */
     double path_loss;
     if ((double)d < d_break) {
         float t = 20.0f * l10;                            /* :179 float32 product */

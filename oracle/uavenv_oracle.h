@@ -15,7 +15,7 @@
  * evaluates `dx**2` on numpy float32 scalars through libm powf() and `np.log10(float32)` through
  * a platform-dependent SIMD/libm routine; both are NOT correctly rounded and differ between
  * machines by 1 ulp (measured here: 0.07 % resp. 47 % of inputs).  The oracle uses the correctly
- * rounded values (dx*dx, (float)log10((double)d)).  Everything else follows the reference's own
+ * rounded values (dx*dx, and orc_log10_f32: float64 evaluation rounded once to float32).  Everything else follows the reference's own
  * operation order and its float32/float64 mix.
  */
 #ifndef UAVENV_ORACLE_H
@@ -116,6 +116,7 @@ long orc_trace_keyed(const OrcConfig* c, int num_envs, uint32_t base, int steps,
                      int32_t* actions_out, float* reset_obs_out, OrcEnv* final_envs);
 
 /* Scalar known-answer helpers. */
+float  orc_log10_f32(float d);
 double orc_rssi_deterministic(const OrcConfig* c, float ux, float uy, float sx, float sy);
 
 #ifdef __cplusplus
