@@ -190,6 +190,30 @@ class BatchedUAVEnv:
                                           self._stream()), self._h)
         return obs, self.reward, self.done
 
+    def rollout(self, num_steps, actions=None, obs_out=None, with_terminal=False):
+        """K steps in ONE launch (uavenv_rollout): `actions` int32 cuda [K, E] or None for the in-kernel random
+        policy.  Returns dict(obs [K,E,D], reward [K,E] f64, reward32, done [K,E] u8, actions [K,E] i32
+        (+ terminal_obs [K,E,D] when with_terminal)).  Bit-identical to K step() calls."""
+        K, E, D, dev = int(num_steps), self.num_envs, self.obs_dim, self.device
+        if actions is not None:
+            assert actions.is_cuda and actions.dtype == torch.int32 and tuple(actions.shape) == (K, E) and actions.is_contiguous()
+        obs = obs_out if obs_out is not None else torch.empty(K, E, D, dtype=torch.float32, device=dev)
+        assert obs.is_contiguous() and tuple(obs.shape) == (K, E, D) and obs.dtype == torch.float32
+        out = dict(obs=obs, reward=torch.empty(K, E, dtype=torch.float64, device=dev),
+                   reward32=torch.empty(K, E, dtype=torch.float32, device=dev),
+                   done=torch.empty(K, E, dtype=torch.uint8, device=dev),
+                   actions=torch.empty(K, E, dtype=torch.int32, device=dev))
+        term = torch.zeros(K, E, D, dtype=torch.float32, device=dev) if with_terminal else None
+        N.check(self.L.uavenv_rollout(self._h, K, self._p(actions), self._p(out["actions"]), self._p(obs),
+                                      self._p(out["reward"]), self._p(out["reward32"]), self._p(out["done"]),
+                                      self._p(term), self._stream()), self._h)
+        if actions is not None:
+            out["actions"] = actions
+        if with_terminal:
+            out["terminal_obs"] = term
+        self.obs = obs[K - 1] if obs_out is None else self.obs
+        return out
+
     def time_steps(self, steps):
         """Average milliseconds per step launch, HIP events on the launch stream (bench.py)."""
         ms = C.c_float()

@@ -321,6 +321,15 @@ extern "C" int uavenv_step_random(UavEnv* e, int32_t* actions_out, float* obs, d
     return step_common(e, nullptr, actions_out, obs, rew, rew32, done, term, stream);
 }
 
+extern "C" int uavenv_rollout(UavEnv* e, int32_t num_steps, const int32_t* actions_dev, int32_t* actions_out, float* obs,
+                              double* rew, float* rew32, uint8_t* done, float* term, void* stream) {
+    if (!e) return UAVENV_E_INVALID;
+    if (num_steps <= 0) return fail(e, UAVENV_E_INVALID, "num_steps must be positive");
+    StepArgs a{actions_dev, actions_out, obs, rew, rew32, done, term, e->num_envs};
+    HIP_TRY(e, launch_rollout(e->G, e->padded_envs, e->consts, e->dev_consts, e->ptrs, a, num_steps, (hipStream_t)stream));
+    return UAVENV_OK;
+}
+
 extern "C" int uavenv_get_state(UavEnv* e, int32_t field, void* dst, size_t bytes, int32_t dst_on_device, void* stream) {
     if (!e || !dst) return UAVENV_E_INVALID;
     void* src = field_ptr(e, field);

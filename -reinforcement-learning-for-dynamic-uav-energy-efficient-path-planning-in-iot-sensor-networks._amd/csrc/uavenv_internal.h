@@ -85,6 +85,8 @@ hipError_t launch_init(int G, int padded_envs, const Consts& c, const Consts* de
                        int32_t grid_w, int32_t grid_h, int32_t n, float start_x, float start_y, hipStream_t s);
 hipError_t launch_reset(int G, int padded_envs, const Consts& c, const Consts* dev_consts, const Ptrs& p, const ResetArgs& a, hipStream_t s);
 hipError_t launch_step(int G, int padded_envs, const Consts& c, const Consts* dev_consts, const Ptrs& p, const StepArgs& a, hipStream_t s);
+hipError_t launch_rollout(int G, int padded_envs, const Consts& c, const Consts* dev_consts, const Ptrs& p, const StepArgs& a,
+                          int32_t num_steps, hipStream_t s);
 hipError_t launch_dump_noise(int G, int padded_envs, const Consts& c, const Consts* dev_consts, const Ptrs& p, float* step_tape,
                              float* reset_tape, int32_t num_envs, hipStream_t s);
 

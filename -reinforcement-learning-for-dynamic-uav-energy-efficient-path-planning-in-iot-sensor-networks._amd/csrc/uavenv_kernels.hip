@@ -546,25 +546,16 @@ __global__ __launch_bounds__(kBlockThreads) void uav_reset_kernel(const Consts* 
 }
 
 // ---------------------------------------------------------------------------------------------
-// step kernel: the hot path
+// One environment step for one lane group: the hot path.  Shared by the single-step kernel (record in
+// global memory) and the fused rollout kernel (record staged in LDS, sensor state kept in registers
+// across steps).  `rec` may point to global memory or LDS.
 // ---------------------------------------------------------------------------------------------
-template <int G>
-__global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_kernel(const Consts* cptr, Ptrs p, StepArgs a) {
-    UAV_CONSTS(cptr);
-    extern __shared__ float lds[];
-#ifdef UAVENV_STAMPS
-    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
+template <int G, typename RecPtr>
+__device__ __forceinline__ void step_once(CRef c, const Ptrs& p, const StepArgs& a, uint32_t env, bool in_batch,
+                                          float* lds_row, RecPtr rec, Sensor& s, bool& wrote_pos, uint32_t& status_or,
+                                          int& action_out) {
     const int gl = group_lane<G>();
-    const uint32_t env = blockIdx.x * (kBlockThreads / G) + uni<G>((int)(threadIdx.x / G));
-    const uint32_t idx = env * G + gl;
-    float* lds_row = lds + (threadIdx.x / G) * c.obs_dim;
-    const bool in_batch = env < (uint32_t)a.num_envs;
-
-    const UavEnvRecord* rp = p.rec + env;
-    Env e = load_env<G>(rp);
-    Sensor s;
-    load_sensor<G>(p, idx, s);
+    Env e = load_env<G>(rec);
     const int n = e.n;
     const bool act = gl < n;
 
@@ -797,7 +788,14 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_ker
 
     // ---- epilogue: the cold part of the record (read late on purpose: see struct Env) -----------------
     asm volatile("" ::: "memory");
-    UavEnvRecord r = p.rec[env];
+    UavEnvRecord r = *rec;
+    if (G == 64) {      // wave-uniform: keep the record in SGPRs (matters when `rec` is LDS: ds_read lands in VGPRs)
+        union { UavEnvRecord r; int w[32]; } u;
+        u.r = r;
+#pragma unroll
+        for (int i = 0; i < 32; i++) u.w[i] = __builtin_amdgcn_readfirstlane(u.w[i]);
+        r = u.r;
+    }
     r.battery = e.battery; r.uav_x = e.ux; r.uav_y = e.uy; r.current_step = e.step;
     r.episode = e.episode; r.env_index = e.env_index; r.num_sensors = e.n; r.grid_w = e.gw; r.grid_h = e.gh;
     r.status |= status_bits;
@@ -828,7 +826,6 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_ker
     }
 
     // ---- SB3 VecEnv auto-reset: episode stats, reset, first observation of the new episode -----------
-    bool wrote_pos = false;
     if (__any(do_reset)) {
         {   // dqn.py:305-331 last_episode_stats (+ Monitor r/l)
             double std_rates;
@@ -858,14 +855,37 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_ker
             double d0 = dist_nearest_with_data<G>(s, act, r.uav_x, r.uav_y);
             if (do_reset) r.prev_dist_nearest = d0;
         }
-        wrote_pos = draw_layout && do_reset;
+        wrote_pos |= draw_layout && do_reset;
     }
+    if (gl == 0) *rec = r;
+    status_or |= r.status;
 
+    action_out = action;
+}
+
+// ---------------------------------------------------------------------------------------------
+// step kernel: one launch = one step() of every environment
+// ---------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_kernel(const Consts* cptr, Ptrs p, StepArgs a) {
+    UAV_CONSTS(cptr);
+    extern __shared__ float lds[];
+#ifdef UAVENV_STAMPS
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int gl = group_lane<G>();
+    const uint32_t env = blockIdx.x * (kBlockThreads / G) + uni<G>((int)(threadIdx.x / G));
+    const uint32_t idx = env * G + gl;
+    float* lds_row = lds + (threadIdx.x / G) * c.obs_dim;
+    const bool in_batch = env < (uint32_t)a.num_envs;
+    Sensor s;
+    load_sensor<G>(p, idx, s);
+    bool wrote_pos = false;
+    uint32_t status_or = 0u;
+    int action = 0;
+    step_once<G>(c, p, a, env, in_batch, lds_row, p.rec + env, s, wrote_pos, status_or, action);
     store_sensor<G>(p, idx, s, wrote_pos);
-    if (gl == 0) {
-        p.rec[env] = r;
-        if (r.status) atomicOr(p.status, r.status);
-    }
+    if (gl == 0 && status_or) atomicOr(p.status, status_or);
 #ifdef UAVENV_STAMPS
     if (p.stamps != nullptr && (threadIdx.x & 63u) == 0) {
         unsigned long long* q = p.stamps + ((size_t)blockIdx.x * (kBlockThreads / 64) + threadIdx.x / 64) * 8;
@@ -875,6 +895,67 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_ker
         q[6] = (unsigned long long)action; q[7] = 0;
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused rollout kernel: K consecutive steps per launch (open-loop actions or the in-kernel random
+// policy).  Sensor state stays in VGPRs and the 128-byte record in LDS for the whole launch; every
+// step still writes its observation / reward / done block ([K][E][...] layout, e.g. K consecutive
+// slots of a replay ring), so the result is bit-identical to K single-step launches.
+// ---------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_rollout_kernel(const Consts* cptr, Ptrs p, StepArgs a,
+                                                                                     int32_t num_steps) {
+    UAV_CONSTS(cptr);
+    extern __shared__ float lds[];
+    const int gl = group_lane<G>();
+    const uint32_t grp = threadIdx.x / G;
+    const uint32_t env = blockIdx.x * (kBlockThreads / G) + uni<G>((int)grp);
+    const uint32_t idx = env * G + gl;
+    float* lds_row = lds + grp * c.obs_dim;
+    // records of this workgroup's environments, after the observation staging rows (16-byte aligned)
+    UavEnvRecord* lrec = reinterpret_cast<UavEnvRecord*>(lds + (((kBlockThreads / G) * c.obs_dim + 3) & ~3)) + grp;
+    const bool in_batch = env < (uint32_t)a.num_envs;
+    Sensor s;
+    load_sensor<G>(p, idx, s);
+    {   // global -> LDS copy of the record: lane j moves dword j (G >= 16: two passes cover 32 dwords)
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(p.rec + env);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(lrec);
+        for (int j = gl; j < 32; j += G) dst[j] = src[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    bool wrote_pos = false;
+    uint32_t status_or = 0u;
+    const size_t E = (size_t)a.num_envs;
+    for (int k = 0; k < num_steps; k++) {
+        StepArgs ak = a;
+        if (a.actions) ak.actions = a.actions + (size_t)k * E;
+        if (a.actions_out) ak.actions_out = a.actions_out + (size_t)k * E;
+        if (a.obs) ak.obs = a.obs + (size_t)k * E * (size_t)c.obs_dim;
+        if (a.term_obs) ak.term_obs = a.term_obs + (size_t)k * E * (size_t)c.obs_dim;
+        if (a.reward) ak.reward = a.reward + (size_t)k * E;
+        if (a.reward32) ak.reward32 = a.reward32 + (size_t)k * E;
+        if (a.done) ak.done = a.done + (size_t)k * E;
+        int action = 0;
+        // Launder the constants pointer every iteration: otherwise LICM hoists all ~90 invariant scalar loads
+        // out of the loop and the SGPR file spills into VGPR lanes (and those into scratch).
+        const Consts* cp = cptr;
+        asm volatile("" : "+s"(cp));
+        CRef ck = *(const __attribute__((address_space(4))) Consts*)(cp);
+        step_once<G>(ck, p, ak, env, in_batch, lds_row, lrec, s, wrote_pos, status_or, action);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    store_sensor<G>(p, idx, s, wrote_pos);
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(lrec);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(p.rec + env);
+        for (int j = gl; j < 32; j += G) dst[j] = src[j];
+    }
+    if (gl == 0 && status_or) atomicOr(p.status, status_or);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -934,6 +1015,14 @@ hipError_t launch_reset(int Gw, int padded_envs, const Consts& c, const Consts* 
 hipError_t launch_step(int Gw, int padded_envs, const Consts& c, const Consts* dc, const Ptrs& p, const StepArgs& a, hipStream_t s) {
     dim3 block(kBlockThreads), grid((unsigned)(padded_envs / (kBlockThreads / Gw)));
     UAV_DISPATCH_G(Gw, (uav_step_kernel<G><<<grid, block, lds_bytes(Gw, c), s>>>(dc, p, a)));
+    return hipGetLastError();
+}
+hipError_t launch_rollout(int Gw, int padded_envs, const Consts& c, const Consts* dc, const Ptrs& p, const StepArgs& a,
+                          int32_t num_steps, hipStream_t s) {
+    dim3 block(kBlockThreads), grid((unsigned)(padded_envs / (kBlockThreads / Gw)));
+    const size_t rows = (((size_t)(kBlockThreads / Gw) * (size_t)c.obs_dim + 3) & ~(size_t)3) * sizeof(float);
+    const size_t bytes = rows + (size_t)(kBlockThreads / Gw) * sizeof(UavEnvRecord);
+    UAV_DISPATCH_G(Gw, (uav_rollout_kernel<G><<<grid, block, bytes, s>>>(dc, p, a, num_steps)));
     return hipGetLastError();
 }
 hipError_t launch_dump_noise(int Gw, int padded_envs, const Consts& c, const Consts* dc, const Ptrs& p, float* step_tape,

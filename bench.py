@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--exchange", choices=["auto", "none", "allgather"], default="auto")
     ap.add_argument("--ring", type=int, default=16, help="replay-ring slots used by the bench")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused", type=int, default=16, help="steps per launch of the additional fused-rollout measurement (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -153,6 +154,28 @@ def main():
     kern_ms = env.time_steps(min(K, 1000))
     torch.cuda.synchronize(dev)
 
+    # Additional measurement (never `value`): the fused rollout entry point, `--fused` steps per launch, writing
+    # every step's obs/reward/done block into consecutive ring slots.  Same results bit for bit.
+    fused = None
+    if args.fused > 0 and exchange == "none":
+        F = args.fused
+        launches = max(1, min(K, 1600) // F)
+        slab = torch.empty(F, E, env.obs_dim, dtype=torch.float32, device=dev)
+        for _ in range(3):
+            env.rollout(F, obs_out=slab)
+        torch.cuda.synchronize(dev)
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f0.record()
+        for _ in range(launches):
+            env.rollout(F, obs_out=slab)
+        f1.record()
+        torch.cuda.synchronize(dev)
+        fms = f0.elapsed_time(f1) / launches
+        fused = {"steps_per_launch": F, "launches": launches, "ms_per_launch": fms,
+                 "env_steps_per_s": E * F / (fms * 1e-3),
+                 "achieved_GBps": algorithmic_bytes_per_env_step(n) * E * F / (fms * 1e-3) / 1e9,
+                 "kernel": "uav_rollout_kernel<64>"}
+
     total_env_steps = E * K * world
     value = total_env_steps / dt
     B = algorithmic_bytes_per_env_step(n)
@@ -180,6 +203,8 @@ def main():
                      "note": "path is VALU/latency bound (Philox + float64 physics per sensor), not HBM bound: "
                              "see DESIGN.md"},
     }
+    if fused:
+        out["fused_rollout"] = fused
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n, (args.grid, args.grid))
         out["cpu_baseline"]["host"] = {"cpu_count": os.cpu_count()}

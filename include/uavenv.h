@@ -192,6 +192,17 @@ int uavenv_step(UavEnv* env, const int32_t* actions_dev, float* obs_out_dev, dou
 int uavenv_step_random(UavEnv* env, int32_t* actions_out_dev, float* obs_out_dev, double* reward_out_dev,
                        float* reward32_out_dev, uint8_t* done_out_dev, float* terminal_obs_dev, void* stream);
 
+/* K consecutive steps in ONE launch (SURVEY 8b "uavenv_step_k"): open-loop actions (actions_dev int32
+ * [K][E]) or, with actions_dev == NULL, the in-kernel uniform-random policy.  Sensor state stays in
+ * registers and the record in LDS for the whole launch, but EVERY step still writes its block:
+ * obs_out_dev [K][E][obs_dim], reward [K][E], done [K][E], actions_out [K][E] (each nullable), e.g. K
+ * consecutive slots of a replay ring.  Bit-identical to K uavenv_step / uavenv_step_random launches.
+ * replaces: the `for _ in range(K): env.step(policy(obs))` loop of uav_env.py:935-960 / SB3
+ * collect_rollouts for policies that do not read the observation (random warm-up, action replay). */
+int uavenv_rollout(UavEnv* env, int32_t num_steps, const int32_t* actions_dev, int32_t* actions_out_dev,
+                   float* obs_out_dev, double* reward_out_dev, float* reward32_out_dev, uint8_t* done_out_dev,
+                   float* terminal_obs_dev, void* stream);
+
 /* ---- state access (checkpoint / parity / the attribute reads of SURVEY 1) -------------------- */
 /* Copies one whole field.  `bytes` must equal the field size; dst/src may be host or device. */
 int uavenv_get_state(UavEnv* env, int32_t field, void* dst, size_t bytes, int32_t dst_on_device, void* stream);

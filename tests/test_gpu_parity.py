@@ -333,3 +333,36 @@ def test_state_roundtrip_and_host_api():
     rc = L.uavenv_step_host(a._h, vp(acts), vp(obs), vp(rew), vp(done), None)
     assert rc == N.E_ACTION
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("n,flags", [(50, 0), (20, 0), (10, 1 | 2 | 4 | 8)])
+def test_fused_rollout_is_bit_identical_to_single_steps(n, flags):
+    """uavenv_rollout (K steps per launch, state in registers / LDS) == K uavenv_step_random launches,
+    including auto-resets inside the fused launch, for the random policy and for given actions."""
+    torch, U, O = _mods()
+    kw = dict(num_sensors=n, max_steps=23, duty_cycle=70.0, grid_size=(130, 130), seed=21, flags=flags)
+    if flags:
+        kw.update(pad_sensors=50, grid_choices=[(100, 100), (200, 200)])
+    E, K = 70, 37
+    a = U.BatchedUAVEnv(E, **kw)
+    b = U.BatchedUAVEnv(E, **kw)
+    assert torch.equal(a.reset(), b.reset())
+    for rep in range(2):
+        ro = a.rollout(K, with_terminal=True)
+        for k in range(K):
+            o, r, d = b.step_random()
+            assert torch.equal(ro["obs"][k], o) and torch.equal(ro["reward"][k], r) and torch.equal(ro["done"][k], d), (rep, k)
+            assert torch.equal(ro["actions"][k], b.actions_taken)
+            m = d.bool()
+            if m.any():
+                assert torch.equal(ro["terminal_obs"][k][m], b.terminal_obs[m])
+        assert ro["done"].any()
+    acts = torch.randint(0, 5, (K, E), dtype=torch.int32, device=a.device)
+    ro = a.rollout(K, actions=acts)
+    for k in range(K):
+        o, r, d = b.step(acts[k])
+        assert torch.equal(ro["obs"][k], o) and torch.equal(ro["reward"][k], r) and torch.equal(ro["done"][k], d), k
+    sa, sb = a.state_dict(), b.state_dict()
+    for key in sa:
+        assert torch.equal(sa[key], sb[key]), key
+    a.close(); b.close()
