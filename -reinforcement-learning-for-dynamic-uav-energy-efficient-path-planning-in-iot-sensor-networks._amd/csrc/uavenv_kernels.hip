@@ -550,7 +550,7 @@ __global__ __launch_bounds__(kBlockThreads) void uav_reset_kernel(const Consts* 
 // global memory) and the fused rollout kernel (record staged in LDS, sensor state kept in registers
 // across steps).  `rec` may point to global memory or LDS.
 // ---------------------------------------------------------------------------------------------
-template <int G, typename RecPtr>
+template <int G, bool kRegs = false, typename RecPtr = UavEnvRecord*>
 __device__ __forceinline__ void step_once(CRef c, const Ptrs& p, const StepArgs& a, uint32_t env, bool in_batch,
                                           float* lds_row, RecPtr rec, Sensor& s, bool& wrote_pos, uint32_t& status_or,
                                           int& action_out) {
@@ -857,7 +857,7 @@ __device__ __forceinline__ void step_once(CRef c, const Ptrs& p, const StepArgs&
         }
         wrote_pos |= draw_layout && do_reset;
     }
-    if (gl == 0) *rec = r;
+    if (kRegs) *rec = r; else if (gl == 0) *rec = r;
     status_or |= r.status;
 
     action_out = action;
@@ -899,8 +899,8 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_ker
 
 // ---------------------------------------------------------------------------------------------
 // fused rollout kernel: K consecutive steps per launch (open-loop actions or the in-kernel random
-// policy).  Sensor state stays in VGPRs and the 128-byte record in LDS for the whole launch; every
-// step still writes its observation / reward / done block ([K][E][...] layout, e.g. K consecutive
+// policy).  Sensor state (VGPRs) and the 128-byte record (SGPRs when G = 64) stay in registers for the
+// whole launch; every step still writes its observation / reward / done block ([K][E][...] layout, e.g. K consecutive
 // slots of a replay ring), so the result is bit-identical to K single-step launches.
 // ---------------------------------------------------------------------------------------------
 template <int G>
@@ -913,19 +913,10 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_rollout_
     const uint32_t env = blockIdx.x * (kBlockThreads / G) + uni<G>((int)grp);
     const uint32_t idx = env * G + gl;
     float* lds_row = lds + grp * c.obs_dim;
-    // records of this workgroup's environments, after the observation staging rows (16-byte aligned)
-    UavEnvRecord* lrec = reinterpret_cast<UavEnvRecord*>(lds + (((kBlockThreads / G) * c.obs_dim + 3) & ~3)) + grp;
     const bool in_batch = env < (uint32_t)a.num_envs;
     Sensor s;
     load_sensor<G>(p, idx, s);
-    {   // global -> LDS copy of the record: lane j moves dword j (G >= 16: two passes cover 32 dwords)
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(p.rec + env);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(lrec);
-        for (int j = gl; j < 32; j += G) dst[j] = src[j];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    UavEnvRecord rr = p.rec[env];
     bool wrote_pos = false;
     uint32_t status_or = 0u;
     const size_t E = (size_t)a.num_envs;
@@ -944,17 +935,13 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_rollout_
         const Consts* cp = cptr;
         asm volatile("" : "+s"(cp));
         CRef ck = *(const __attribute__((address_space(4))) Consts*)(cp);
-        step_once<G>(ck, p, ak, env, in_batch, lds_row, lrec, s, wrote_pos, status_or, action);
+        step_once<G, true>(ck, p, ak, env, in_batch, lds_row, &rr, s, wrote_pos, status_or, action);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     store_sensor<G>(p, idx, s, wrote_pos);
-    {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(lrec);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(p.rec + env);
-        for (int j = gl; j < 32; j += G) dst[j] = src[j];
-    }
+    if (gl == 0) p.rec[env] = rr;
     if (gl == 0 && status_or) atomicOr(p.status, status_or);
 }
 
@@ -1020,9 +1007,7 @@ hipError_t launch_step(int Gw, int padded_envs, const Consts& c, const Consts* d
 hipError_t launch_rollout(int Gw, int padded_envs, const Consts& c, const Consts* dc, const Ptrs& p, const StepArgs& a,
                           int32_t num_steps, hipStream_t s) {
     dim3 block(kBlockThreads), grid((unsigned)(padded_envs / (kBlockThreads / Gw)));
-    const size_t rows = (((size_t)(kBlockThreads / Gw) * (size_t)c.obs_dim + 3) & ~(size_t)3) * sizeof(float);
-    const size_t bytes = rows + (size_t)(kBlockThreads / Gw) * sizeof(UavEnvRecord);
-    UAV_DISPATCH_G(Gw, (uav_rollout_kernel<G><<<grid, block, bytes, s>>>(dc, p, a, num_steps)));
+    UAV_DISPATCH_G(Gw, (uav_rollout_kernel<G><<<grid, block, lds_bytes(Gw, c), s>>>(dc, p, a, num_steps)));
     return hipGetLastError();
 }
 hipError_t launch_dump_noise(int Gw, int padded_envs, const Consts& c, const Consts* dc, const Ptrs& p, float* step_tape,
