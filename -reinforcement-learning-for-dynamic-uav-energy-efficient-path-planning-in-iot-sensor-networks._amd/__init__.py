@@ -10,9 +10,10 @@ from . import _native
 from ._native import (FLAG_AUTO_RESET, FLAG_FAR_START, FLAG_JAIN_BONUS, FLAG_PROX_SHAPING, FLAG_RANDOM_LAYOUT,
                       UavEnvConfig, UavEnvError, default_config)
 from .batched_env import BatchedUAVEnv, config_from_kwargs
+from .frame_stack import FrameStack
 from .gym_env import CURRICULUM_STAGES, DomainRandEnv, UAVEnvironment
 from .replay import TransitionRing
 from .vec_env import UAVVecEnv
 
-__all__ = ["BatchedUAVEnv", "UAVEnvironment", "DomainRandEnv", "UAVVecEnv", "TransitionRing", "CURRICULUM_STAGES", "UavEnvConfig", "UavEnvError", "default_config", "config_from_kwargs",
+__all__ = ["BatchedUAVEnv", "UAVEnvironment", "DomainRandEnv", "UAVVecEnv", "TransitionRing", "FrameStack", "CURRICULUM_STAGES", "UavEnvConfig", "UavEnvError", "default_config", "config_from_kwargs",
            "FLAG_AUTO_RESET", "FLAG_FAR_START", "FLAG_JAIN_BONUS", "FLAG_PROX_SHAPING", "FLAG_RANDOM_LAYOUT"]

@@ -148,6 +148,16 @@ class BatchedUAVEnv:
         self._tapes = (step_tape, reset_tape)        # keep alive
         N.check(self.L.uavenv_set_noise_tape(self._h, self._p(step_tape), self._p(reset_tape)), self._h)
 
+    def set_terminal_pool(self, pool=None, counter=None, index_out=None):
+        """pool float32 cuda [rows, D]; counter int32/uint32 cuda [1]; index_out int32 cuda [E] (or all None)."""
+        if pool is not None:
+            assert pool.is_cuda and pool.dtype == torch.float32 and pool.is_contiguous() and pool.shape[1] == self.obs_dim
+            assert counter.is_cuda and counter.numel() == 1 and counter.element_size() == 4
+            assert index_out is None or (index_out.is_cuda and index_out.dtype == torch.int32 and index_out.numel() == self.num_envs)
+        self._term_pool = (pool, counter, index_out)     # keep alive
+        N.check(self.L.uavenv_set_terminal_pool(self._h, self._p(pool), 0 if pool is None else pool.shape[0],
+                                                self._p(counter), self._p(index_out)), self._h)
+
     def dump_noise(self):
         E, G = self.num_envs, self.lane_stride
         st = torch.empty(E, 6, G, dtype=torch.float32, device=self.device)

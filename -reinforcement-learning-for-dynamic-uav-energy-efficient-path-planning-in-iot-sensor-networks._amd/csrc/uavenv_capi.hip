@@ -28,6 +28,7 @@ struct UavEnv {
     int32_t* h_actions_dev = nullptr; float* h_obs_dev = nullptr; double* h_rew_dev = nullptr;
     uint8_t* h_done_dev = nullptr; float* h_term_dev = nullptr; uint8_t* h_mask_dev = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float* term_pool = nullptr; uint32_t* term_counter = nullptr; int32_t* term_index = nullptr; int32_t term_rows = 0;
     std::string err;
 };
 
@@ -305,7 +306,8 @@ extern "C" int uavenv_reset(UavEnv* e, const uint8_t* mask_dev, float* obs_out_d
 static int step_common(UavEnv* e, const int32_t* actions, int32_t* actions_out, float* obs, double* rew, float* rew32,
                        uint8_t* done, float* term, void* stream) {
     if (!e) return UAVENV_E_INVALID;
-    StepArgs a{actions, actions_out, obs, rew, rew32, done, term, e->num_envs};
+    StepArgs a{actions, actions_out, obs, rew, rew32, done, term, e->num_envs,
+               e->term_pool, e->term_counter, e->term_index, e->term_rows};
     HIP_TRY(e, launch_step(e->G, e->padded_envs, e->consts, e->dev_consts, e->ptrs, a, (hipStream_t)stream));
     return UAVENV_OK;
 }
@@ -325,8 +327,28 @@ extern "C" int uavenv_rollout(UavEnv* e, int32_t num_steps, const int32_t* actio
                               double* rew, float* rew32, uint8_t* done, float* term, void* stream) {
     if (!e) return UAVENV_E_INVALID;
     if (num_steps <= 0) return fail(e, UAVENV_E_INVALID, "num_steps must be positive");
-    StepArgs a{actions_dev, actions_out, obs, rew, rew32, done, term, e->num_envs};
+    StepArgs a{actions_dev, actions_out, obs, rew, rew32, done, term, e->num_envs,
+               e->term_pool, e->term_counter, nullptr, e->term_rows};   // per-step indices are not kept by rollouts
     HIP_TRY(e, launch_rollout(e->G, e->padded_envs, e->consts, e->dev_consts, e->ptrs, a, num_steps, (hipStream_t)stream));
+    return UAVENV_OK;
+}
+
+extern "C" int uavenv_set_terminal_pool(UavEnv* e, float* pool_dev, int32_t rows, uint32_t* counter_dev, int32_t* index_out_dev) {
+    if (!e) return UAVENV_E_INVALID;
+    if (pool_dev != nullptr && (rows <= 0 || counter_dev == nullptr))
+        return fail(e, UAVENV_E_INVALID, "terminal pool needs rows > 0 and a counter");
+    e->term_pool = pool_dev; e->term_rows = rows; e->term_counter = counter_dev; e->term_index = index_out_dev;
+    return UAVENV_OK;
+}
+
+extern "C" int uavenv_frame_stack(float* stacked_dev, const float* obs_dev, const uint8_t* done_dev,
+                                  const float* terminal_obs_dev, float* terminal_stacked_dev, int32_t num_envs,
+                                  int32_t num_frames, int32_t obs_dim, void* stream) {
+    if (!stacked_dev || !obs_dev || num_envs <= 0) return UAVENV_E_INVALID;
+    hipError_t st = launch_frame_stack(stacked_dev, obs_dev, done_dev, terminal_obs_dev, terminal_stacked_dev, num_envs,
+                                       num_frames, obs_dim, (hipStream_t)stream);
+    if (st != hipSuccess) return fail(nullptr, st == hipErrorInvalidValue ? UAVENV_E_INVALID : UAVENV_E_HIP,
+                                      std::string("frame_stack: ") + hipGetErrorString(st));
     return UAVENV_OK;
 }
 

@@ -72,6 +72,12 @@ struct StepArgs {
     uint8_t* done;
     float* term_obs;
     int32_t num_envs;           // E (arrays are padded to a whole number of workgroups)
+    // optional terminal-observation pool (uavenv_set_terminal_pool): terminal rows go to
+    // term_pool[atomicAdd(term_counter, 1) % term_rows] and the row index to term_index[env] (-1 if not done)
+    float* term_pool;
+    uint32_t* term_counter;
+    int32_t* term_index;
+    int32_t term_rows;
 };
 
 struct ResetArgs {
@@ -87,6 +93,8 @@ hipError_t launch_reset(int G, int padded_envs, const Consts& c, const Consts* d
 hipError_t launch_step(int G, int padded_envs, const Consts& c, const Consts* dev_consts, const Ptrs& p, const StepArgs& a, hipStream_t s);
 hipError_t launch_rollout(int G, int padded_envs, const Consts& c, const Consts* dev_consts, const Ptrs& p, const StepArgs& a,
                           int32_t num_steps, hipStream_t s);
+hipError_t launch_frame_stack(float* stacked, const float* obs, const uint8_t* done, const float* terminal_obs,
+                              float* terminal_stacked, int32_t num_envs, int32_t k, int32_t D, hipStream_t s);
 hipError_t launch_dump_noise(int G, int padded_envs, const Consts& c, const Consts* dev_consts, const Ptrs& p, float* step_tape,
                              float* reset_tape, int32_t num_envs, hipStream_t s);
 

@@ -783,6 +783,16 @@ __device__ __forceinline__ void step_once(CRef c, const Ptrs& p, const StepArgs&
             if (do_reset) dst = a.term_obs ? a.term_obs + env * (size_t)c.obs_dim : nullptr;
             else dst = a.obs ? a.obs + env * (size_t)c.obs_dim : nullptr;
         }
+        if (a.term_pool != nullptr) {          // kernel-uniform: terminal rows go to a compact pool instead
+            int row = -1;
+            if (__any(do_reset & in_batch)) {
+                uint32_t t = 0u;
+                if (do_reset & in_batch & (gl == 0)) t = atomicAdd(a.term_counter, 1u) % (uint32_t)a.term_rows;
+                t = gshfl<G>(t, 0);
+                if (do_reset & in_batch) { row = (int)t; dst = a.term_pool + (size_t)t * (size_t)c.obs_dim; }
+            }
+            if (in_batch && gl == 0 && a.term_index != nullptr) a.term_index[env] = row;
+        }
         observe<G>(c, s, n, e.gw, e.gh, e.ux, e.uy, e.battery, act, true, det, z.zD, z.zE, dst, lds_row);   // :488
     }
 
@@ -929,6 +939,7 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_rollout_
         if (a.reward) ak.reward = a.reward + (size_t)k * E;
         if (a.reward32) ak.reward32 = a.reward32 + (size_t)k * E;
         if (a.done) ak.done = a.done + (size_t)k * E;
+        if (a.term_index) ak.term_index = a.term_index + (size_t)k * E;
         int action = 0;
         // Launder the constants pointer every iteration: otherwise LICM hoists all ~90 invariant scalar loads
         // out of the loop and the SGPR file spills into VGPR lanes (and those into scratch).
@@ -973,6 +984,60 @@ __global__ __launch_bounds__(kBlockThreads) void uav_dump_noise_kernel(const Con
         float* t = reset_tape + env * (size_t)(UAVENV_RTAPE_SLOTS * G) + gl;
         t[0 * G] = u24(w.w0); t[1 * G] = zD; t[2 * G] = zE;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// frame stack: SB3 VecFrameStack semantics on device, in place.
+//   stacked[e] = [frame_{t-k+1} | ... | frame_t]  (k frames of D floats, oldest first)
+//   step:  shift left by one frame, append obs[e]; where done[e], the older frames are zeroed first
+//          (the appended observation is then the first one of the new episode);
+//   terminal_stacked (optional): for done envs, [old frames shifted | terminal_obs] = SB3's stacked
+//          "terminal_observation".
+// One wavefront owns one environment row: it loads the whole shifted row into registers before it
+// stores, so the in-place shift is race free; all accesses are contiguous dwords.
+// ---------------------------------------------------------------------------------------------
+constexpr int kFsMaxPerLane = 40;      // 64 lanes x 40 floats = 2560 floats per row (k*D <= 2560)
+
+__global__ __launch_bounds__(kBlockThreads) void uav_frame_stack_kernel(float* stacked, const float* obs, const uint8_t* done,
+                                                                      const float* terminal_obs, float* terminal_stacked,
+                                                                      int32_t num_envs, int32_t k, int32_t D) {
+    const int lane = threadIdx.x & 63;
+    const int env = blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6);
+    if (env >= num_envs) return;
+    const int row = k * D, keep = row - D;
+    float* s = stacked + (size_t)env * row;
+    const bool dn = done != nullptr && done[env] != 0;
+    float v[kFsMaxPerLane];
+#pragma unroll
+    for (int j = 0; j < kFsMaxPerLane; j++) {
+        const int i = lane + 64 * j;
+        v[j] = (i < keep) ? s[i + D] : 0.0f;              // old frames 1..k-1 -> positions 0..k-2
+    }
+    if (dn && terminal_stacked != nullptr && terminal_obs != nullptr) {
+        float* t = terminal_stacked + (size_t)env * row;
+        const float* to = terminal_obs + (size_t)env * D;
+#pragma unroll
+        for (int j = 0; j < kFsMaxPerLane; j++) {
+            const int i = lane + 64 * j;
+            if (i < keep) t[i] = v[j];
+            else if (i < row) t[i] = to[i - keep];
+        }
+    }
+    const float* o = obs + (size_t)env * D;
+#pragma unroll
+    for (int j = 0; j < kFsMaxPerLane; j++) {
+        const int i = lane + 64 * j;
+        if (i < keep) s[i] = dn ? 0.0f : v[j];
+        else if (i < row) s[i] = o[i - keep];
+    }
+}
+
+hipError_t launch_frame_stack(float* stacked, const float* obs, const uint8_t* done, const float* terminal_obs,
+                              float* terminal_stacked, int32_t num_envs, int32_t k, int32_t D, hipStream_t s) {
+    if (k < 1 || D < 1 || (long long)k * D > 64LL * kFsMaxPerLane) return hipErrorInvalidValue;
+    dim3 block(kBlockThreads), grid((unsigned)((num_envs + 3) / 4));
+    uav_frame_stack_kernel<<<grid, block, 0, s>>>(stacked, obs, done, terminal_obs, terminal_stacked, num_envs, k, D);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -8,25 +8,41 @@ slices arrive through one in-place `all_gather_into_tensor` per tensor (RCCL ove
 backend is "nccl"; "gloo" on CPU for the multi-process tests).  The collective is issued on a side
 stream so that it overlaps the next environment step.
 
-next_obs is not stored: it is the following slot's obs, except where `done`, where the
-terminal observation is kept in a small side table (SB3's "terminal_observation" semantics).
+next_obs is not stored: it is the following slot's obs, except where `done` (the env was auto-reset,
+so the following slot holds the first observation of the NEXT episode): there the terminal observation
+is looked up in a compact pool that the step kernel fills directly (uavenv_set_terminal_pool; SB3's
+"terminal_observation" semantics, `terminated` is always False in this environment so every episode end
+bootstraps from its terminal observation).  The pool is local to a rank: transitions of other ranks that
+end an episode are returned with valid=False (about 1 in 1500) and must be masked out of the loss.
 """
 import torch
 import torch.distributed as dist
 
 
 class TransitionRing:
-    def __init__(self, capacity, envs_per_rank, obs_dim, device, world_size=1, rank=0, group=None):
+    def __init__(self, capacity, envs_per_rank, obs_dim, device, world_size=1, rank=0, group=None, terminal_rows=None):
         self.capacity, self.E, self.D = int(capacity), int(envs_per_rank), int(obs_dim)
         self.world, self.rank, self.group = int(world_size), int(rank), group
         self.device = torch.device(device)
         # [slot][rank][env][...]: a rank's block is contiguous => in-place all-gather
         self.obs = torch.zeros(self.capacity, self.world, self.E, self.D, dtype=torch.float32, device=self.device)
         self.aux = torch.zeros(self.capacity, self.world, self.E, 4, dtype=torch.float32, device=self.device)
+        # terminal-observation pool (rows recycle; sized so that a row outlives the ring slot that refers to it:
+        # ~E/1400 episodes end per step)
+        self.terminal_rows = int(terminal_rows) if terminal_rows is not None else max(1024, (self.capacity * self.E) // 256)
+        self.term_pool = torch.zeros(self.terminal_rows, self.D, dtype=torch.float32, device=self.device)
+        self.term_counter = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.term_index = torch.full((self.E,), -1, dtype=torch.int32, device=self.device)
+        self._attached = False
         self.head = 0                 # next slot to write
         self.size = 0                 # number of valid slots
         self._pending = [None] * self.capacity
         self._comm_stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+
+    def attach(self, env):
+        """Let `env` (BatchedUAVEnv) write terminal observations straight into this ring's pool."""
+        env.set_terminal_pool(self.term_pool, self.term_counter, self.term_index)
+        self._attached = True
 
     # ---- producer side -----------------------------------------------------------------------
     def local_obs_slot(self, slot=None):
@@ -48,6 +64,7 @@ class TransitionRing:
         aux[:, 0] = actions.to(torch.float32)
         aux[:, 1] = reward.to(torch.float32)
         aux[:, 2] = done.to(torch.float32)
+        aux[:, 3] = self.term_index.to(torch.float32) if self._attached else -1.0
         if self.world > 1:
             if self._comm_stream is not None:
                 self._comm_stream.wait_stream(torch.cuda.current_stream(self.device))
@@ -90,5 +107,11 @@ class TransitionRing:
         e = torch.randint(0, self.E, (batch_size,), generator=generator, device=self.device)
         aux = self.aux[slot, r, e]
         assert newest != oldest or self.size == 1
-        return dict(obs=self.obs[slot, r, e], action=aux[:, 0].long(), reward=aux[:, 1], done=aux[:, 2] > 0.5,
-                    next_obs=self.obs[nxt, r, e])
+        done = aux[:, 2] > 0.5
+        next_obs = self.obs[nxt, r, e]
+        tidx = aux[:, 3].long()
+        have_term = done & (tidx >= 0) & (r == self.rank)
+        next_obs = torch.where(have_term.unsqueeze(1), self.term_pool[tidx.clamp(min=0)], next_obs)
+        valid = ~done | have_term
+        return dict(obs=self.obs[slot, r, e], action=aux[:, 0].long(), reward=aux[:, 1], done=done,
+                    next_obs=next_obs, valid=valid)

@@ -203,6 +203,22 @@ int uavenv_rollout(UavEnv* env, int32_t num_steps, const int32_t* actions_dev, i
                    float* obs_out_dev, double* reward_out_dev, float* reward32_out_dev, uint8_t* done_out_dev,
                    float* terminal_obs_dev, void* stream);
 
+/* Optional compact pool for terminal observations (replay buffers need next_obs = terminal observation on
+ * truncated transitions, SB3 "terminal_observation"; ~1 in 1500 steps per env truncates).  When set, a
+ * truncating env writes its terminal row to pool_dev[atomicAdd(*counter_dev, 1) % rows][obs_dim] instead of
+ * terminal_obs_dev[env], and index_out_dev[env] (int32 [E], nullable) receives that row or -1.
+ * pool_dev == NULL restores the per-env terminal_obs_dev rows. */
+int uavenv_set_terminal_pool(UavEnv* env, float* pool_dev, int32_t rows, uint32_t* counter_dev, int32_t* index_out_dev);
+
+/* ---- frame stack (the caller directly above the path in the trainer: dqn.py:1278) ------------------ */
+/* replaces: SB3 VecFrameStack(n_stack=k).step_wait on device, in place.  stacked_dev float [E][k*obs_dim]
+ * (oldest frame first) is shifted left by one frame and obs_dev [E][obs_dim] appended; where done_dev[e]
+ * the older frames are zeroed first.  terminal_stacked_dev (nullable, with terminal_obs_dev) receives, for
+ * done envs, SB3's stacked "terminal_observation" = [old frames shifted | terminal_obs].  k*obs_dim <= 2560.
+ * Needs no UavEnv handle. */
+int uavenv_frame_stack(float* stacked_dev, const float* obs_dev, const uint8_t* done_dev, const float* terminal_obs_dev,
+                       float* terminal_stacked_dev, int32_t num_envs, int32_t num_frames, int32_t obs_dim, void* stream);
+
 /* ---- state access (checkpoint / parity / the attribute reads of SURVEY 1) -------------------- */
 /* Copies one whole field.  `bytes` must equal the field size; dst/src may be host or device. */
 int uavenv_get_state(UavEnv* env, int32_t field, void* dst, size_t bytes, int32_t dst_on_device, void* stream);

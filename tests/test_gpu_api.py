@@ -172,3 +172,70 @@ def test_vec_env_sb3_contract():
         dr.step(np.zeros(4, dtype=np.int64))
     assert all(g in [(100, 100), (200, 200), (300, 300), (400, 400)] for g in dr.get_attr("grid_size"))
     dr.close()
+
+
+def _sb3_frame_stack_step(stacked, obs, done, term, D):
+    """numpy restatement of SB3 2.x StackedObservations.update for flat Box observations
+    (stable_baselines3/common/vec_env/stacked_observations.py; SB3 itself is not installed here, so this
+    row's parity is pinned by this restatement only -- "parity unpinned" by the reference's own files)."""
+    stacked = np.roll(stacked, -D, axis=-1)
+    terminal = {}
+    for i in np.nonzero(done)[0]:
+        terminal[i] = np.concatenate([stacked[i, :-D], term[i]])
+        stacked[i] = 0
+    stacked[:, -D:] = obs
+    return stacked, terminal
+
+
+@pytest.mark.parametrize("k,n", [(4, 50), (10, 50), (4, 20)])
+def test_frame_stack_matches_sb3_semantics(k, n):
+    torch, U, O = _mods()
+    E = 37
+    env = U.BatchedUAVEnv(E, num_sensors=n, max_steps=9, seed=2)
+    D = env.obs_dim
+    fs = U.FrameStack(E, D, k, env.device)
+    obs = env.reset()
+    got = fs.reset(obs).cpu().numpy()
+    ref = np.zeros((E, k * D), np.float32); ref[:, -D:] = obs.cpu().numpy()
+    assert np.array_equal(got, ref)
+    for s in range(40):
+        o, r, d = env.step_random()
+        got = fs.step(o, d, env.terminal_obs).cpu().numpy()
+        ref, terminal = _sb3_frame_stack_step(ref, o.cpu().numpy(), d.cpu().numpy(), env.terminal_obs.cpu().numpy(), D)
+        assert np.array_equal(got, ref), s
+        ts = fs.terminal_stacked.cpu().numpy()
+        for i, row in terminal.items():
+            assert np.array_equal(ts[i], row), (s, i)
+    env.close()
+
+
+def test_replay_ring_with_terminal_pool():
+    """Kernel-written observations + terminal pool: sampled transitions are (obs_t, a_t, r_t, obs_{t+1}) with
+    next_obs = the TERMINAL observation where the episode ended (SB3 replay semantics), checked against the oracle."""
+    torch, U, O = _mods()
+    E, steps = 48, 60
+    kw = dict(num_sensors=20, max_steps=13, duty_cycle=70.0, grid_size=(90, 90), seed=8)
+    env = U.BatchedUAVEnv(E, **kw)
+    want = O.trace_keyed(O.default_config(**kw), E, steps)
+    ring = U.TransitionRing(steps + 1, E, env.obs_dim, env.device)
+    ring.attach(env)
+    env.reset(); ring.local_obs_slot().copy_(env.obs)
+    ring.commit(torch.zeros(E, device=env.device), torch.zeros(E, device=env.device), torch.zeros(E, device=env.device))
+    for s in range(steps):
+        _, _, done = env.step_random(obs_out=ring.local_obs_slot())
+        ring.commit(env.actions_taken, env.reward32, done)
+    torch.cuda.synchronize()
+    # slot s+1 holds obs after step s together with (action, reward, done) OF step s
+    obs = ring.obs[:, 0].cpu().numpy(); aux = ring.aux[:, 0].cpu().numpy(); pool = ring.term_pool.cpu().numpy()
+    assert np.array_equal(obs[0], want["reset_obs"])
+    n_term = 0
+    for s in range(steps):
+        assert np.array_equal(obs[s + 1], want["obs"][s])
+        assert np.array_equal(aux[s + 1, :, 0].astype(np.int32), want["actions"][s])
+        assert np.array_equal(aux[s + 1, :, 2] > 0.5, want["done"][s].astype(bool))
+        for k in np.nonzero(want["done"][s])[0]:
+            row = int(aux[s + 1, k, 3]); assert row >= 0
+            assert np.array_equal(pool[row], want["term_obs"][s, k]); n_term += 1
+        assert np.all(aux[s + 1, ~want["done"][s].astype(bool), 3] == -1)
+    assert n_term >= E * 3
+    env.close()

@@ -67,6 +67,13 @@ def test_transition_ring_single_rank_cpu():
     assert b["obs"].shape == (64, 5) and b["next_obs"].shape == (64, 5)
     assert torch.all(b["next_obs"][:, 0] == b["obs"][:, 0] + 1)         # successor slot = next step
     assert torch.equal(b["reward"], b["obs"][:, 0] * 10.0)
+    # done transitions without a pool entry are flagged invalid (next_obs would be the next episode's first obs)
+    assert torch.equal(b["valid"], ~b["done"])
+    ring.term_pool[5] = 77.0
+    ring.aux[:, 0, 1, 3] = 5.0                       # env 1 (always `done`) points at pool row 5
+    b = ring.sample(256, generator=torch.Generator().manual_seed(1))
+    m = b["done"]
+    assert m.any() and b["valid"].all() and torch.all(b["next_obs"][m] == 77.0)
 
 
 def _ring_worker(rank, world, port, q):
