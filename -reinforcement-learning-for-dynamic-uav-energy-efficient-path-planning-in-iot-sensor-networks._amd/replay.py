@@ -115,3 +115,40 @@ class TransitionRing:
         valid = ~done | have_term
         return dict(obs=self.obs[slot, r, e], action=aux[:, 0].long(), reward=aux[:, 1], done=done,
                     next_obs=next_obs, valid=valid)
+
+
+    def sample_stacked(self, batch_size, n_stack, generator=None):
+        """Like sample(), but observations are frame stacks of `n_stack` frames gathered from the ring on the
+        fly (SB3 VecFrameStack layout: [oldest | ... | newest], frames from before the episode start zeroed),
+        so the replay stores each frame ONCE instead of n_stack times (dqn.py:1085 budgets 2 x 612 floats per
+        transition for the stacked copies)."""
+        assert self.size >= n_stack + 1
+        self.drain()
+        k = int(n_stack)
+        n_slots = self.size - 1
+        oldest = (self.head - self.size) % self.capacity
+        j = torch.randint(0, n_slots, (batch_size,), generator=generator, device=self.device)
+        slot = (oldest + j) % self.capacity
+        r = torch.randint(0, self.world, (batch_size,), generator=generator, device=self.device)
+        e = torch.randint(0, self.E, (batch_size,), generator=generator, device=self.device)
+        back = torch.arange(k - 1, -1, -1, device=self.device)                      # k-1 ... 0 (oldest first)
+        fs = (slot.unsqueeze(1) - back.unsqueeze(0)) % self.capacity                # [B, k] frame slots
+        in_ring = (j.unsqueeze(1) - back.unsqueeze(0)) >= 0                         # frame older than the ring start?
+        rr, ee = r.unsqueeze(1).expand(-1, k), e.unsqueeze(1).expand(-1, k)
+        frames = self.obs[fs, rr, ee]                                               # [B, k, D]
+        dn = self.aux[fs, rr, ee, 2] > 0.5                                          # frame is the first of an episode
+        # frame i (i < k-1) is valid iff no episode start among frames i+1 .. k-1
+        later_start = torch.flip(torch.cumsum(torch.flip(dn[:, 1:], [1]).int(), 1), [1]) > 0     # [B, k-1]
+        valid_f = torch.cat([~later_start, torch.ones(batch_size, 1, dtype=torch.bool, device=self.device)], 1) & in_ring
+        frames = frames * valid_f.unsqueeze(2)
+        obs = frames.reshape(batch_size, k * self.D)
+        nxt = (slot + 1) % self.capacity
+        aux = self.aux[nxt, r, e]                  # (action, reward, done) OF the transition slot -> nxt
+        done = aux[:, 2] > 0.5
+        tidx = aux[:, 3].long()
+        have_term = done & (tidx >= 0) & (r == self.rank)
+        last = torch.where(have_term.unsqueeze(1), self.term_pool[tidx.clamp(min=0)], self.obs[nxt, r, e])
+        # next stack = [frames 1..k-1 | newest]; after an auto-reset the real next state is the terminal observation
+        next_obs = torch.cat([frames[:, 1:].reshape(batch_size, (k - 1) * self.D), last], 1)
+        return dict(obs=obs, action=aux[:, 0].long(), reward=aux[:, 1], done=done, next_obs=next_obs,
+                    valid=~done | have_term)

@@ -239,3 +239,40 @@ def test_replay_ring_with_terminal_pool():
         assert np.all(aux[s + 1, ~want["done"][s].astype(bool), 3] == -1)
     assert n_term >= E * 3
     env.close()
+
+
+def test_stacked_sampling_equals_frame_stack():
+    """TransitionRing.sample_stacked gathers the same stacks the device FrameStack produced while acting."""
+    torch, U, O = _mods()
+    E, steps, k = 24, 50, 4
+    env = U.BatchedUAVEnv(E, num_sensors=10, max_steps=11, seed=3)
+    D = env.obs_dim
+    ring = U.TransitionRing(steps + 1, E, D, env.device); ring.attach(env)
+    fs = U.FrameStack(E, D, k, env.device)
+    obs = env.reset(); ring.local_obs_slot().copy_(obs)
+    z = torch.zeros(E, device=env.device); ring.commit(z, z, z)
+    stacks = [fs.reset(obs).clone()]; terms = [None]
+    for s in range(steps):
+        o, r, d = env.step_random(obs_out=ring.local_obs_slot())
+        ring.commit(env.actions_taken, env.reward32, d)
+        # (with the pool attached the kernel writes terminal rows into ring.term_pool, not env.terminal_obs)
+        stacks.append(fs.step(o, d, None).clone()); terms.append((d.clone(), ring.term_index.clone()))
+    g = torch.Generator(device=env.device).manual_seed(0)
+    b = ring.sample_stacked(4096, k, generator=g)
+    g = torch.Generator(device=env.device).manual_seed(0)          # replay the index draws
+    n_slots = ring.size - 1
+    j = torch.randint(0, n_slots, (4096,), generator=g, device=env.device)
+    _ = torch.randint(0, 1, (4096,), generator=g, device=env.device)
+    e = torch.randint(0, E, (4096,), generator=g, device=env.device)
+    checked_term = 0
+    for i in range(0, 4096, 7):
+        s, ei = int(j[i]), int(e[i])
+        assert torch.equal(b["obs"][i], stacks[s][ei]), (i, s, ei)
+        d, tix = terms[s + 1]
+        if d[ei]:      # SB3's stacked terminal_observation: [old frames shifted | terminal obs]
+            want = torch.cat([stacks[s][ei][D:], ring.term_pool[int(tix[ei])]])
+            assert torch.equal(b["next_obs"][i], want); checked_term += 1
+        else:
+            assert torch.equal(b["next_obs"][i], stacks[s + 1][ei])
+    assert checked_term > 5 and b["valid"].all()
+    env.close()
