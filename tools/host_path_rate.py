@@ -1,0 +1,44 @@
+"""GPU box: PCIe-inclusive rates of the host-buffer boundaries (never used for bench `value`):
+uavenv_step_host (C ABI, synchronous numpy in/out) and UAVVecEnv.step (SB3 contract)."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import uavenv_amd as U  # noqa: E402
+from uavenv_amd import _native as N  # noqa: E402
+
+E, n, steps = 4096, 50, 300
+env = U.BatchedUAVEnv(E, num_sensors=n, seed=0)
+env.reset()
+L = N.lib()
+obs = np.zeros((E, env.obs_dim), np.float32); rew = np.zeros(E); done = np.zeros(E, np.uint8)
+acts = np.random.default_rng(0).integers(0, 5, size=(steps, E)).astype(np.int32)
+vp = lambda x: x.ctypes.data_as(C.c_void_p)
+torch.cuda.synchronize()
+for s in range(20):
+    N.check(L.uavenv_step_host(env._h, vp(acts[s]), vp(obs), vp(rew), vp(done), None), env._h)
+t0 = time.perf_counter()
+for s in range(steps):
+    N.check(L.uavenv_step_host(env._h, vp(acts[s]), vp(obs), vp(rew), vp(done), None), env._h)
+dt = time.perf_counter() - t0
+out = {"uavenv_step_host": {"env_steps_per_s": E * steps / dt, "us_per_vector_step": dt / steps * 1e6,
+                            "bytes_over_pcie_per_step": E * (4 + env.obs_dim * 4 + 8 + 1)}}
+env.close()
+venv = U.UAVVecEnv(E, num_sensors=n, seed=0)
+venv.reset()
+for s in range(20):
+    venv.step_async(acts[s]); venv.step_wait()
+t0 = time.perf_counter()
+for s in range(steps):
+    venv.step_async(acts[s]); venv.step_wait()
+dt = time.perf_counter() - t0
+out["UAVVecEnv.step"] = {"env_steps_per_s": E * steps / dt, "us_per_vector_step": dt / steps * 1e6}
+venv.close()
+print(json.dumps(out))
