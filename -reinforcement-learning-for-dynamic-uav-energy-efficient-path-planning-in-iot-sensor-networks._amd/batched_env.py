@@ -158,6 +158,13 @@ class BatchedUAVEnv:
         N.check(self.L.uavenv_set_terminal_pool(self._h, self._p(pool), 0 if pool is None else pool.shape[0],
                                                 self._p(counter), self._p(index_out)), self._h)
 
+    def set_aux_output(self, aux=None):
+        """aux float32 cuda [E, 4] (or [K, E, 4] for rollouts): (action, reward, done, terminal row) per step; None disables."""
+        if aux is not None:
+            assert aux.is_cuda and aux.dtype == torch.float32 and aux.is_contiguous() and aux.shape[-1] == 4
+        self._aux = aux
+        N.check(self.L.uavenv_set_aux_output(self._h, self._p(aux)), self._h)
+
     def dump_noise(self):
         E, G = self.num_envs, self.lane_stride
         st = torch.empty(E, 6, G, dtype=torch.float32, device=self.device)

@@ -29,6 +29,7 @@ struct UavEnv {
     uint8_t* h_done_dev = nullptr; float* h_term_dev = nullptr; uint8_t* h_mask_dev = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float* term_pool = nullptr; uint32_t* term_counter = nullptr; int32_t* term_index = nullptr; int32_t term_rows = 0;
+    float* aux_out = nullptr;
     std::string err;
 };
 
@@ -307,7 +308,7 @@ static int step_common(UavEnv* e, const int32_t* actions, int32_t* actions_out, 
                        uint8_t* done, float* term, void* stream) {
     if (!e) return UAVENV_E_INVALID;
     StepArgs a{actions, actions_out, obs, rew, rew32, done, term, e->num_envs,
-               e->term_pool, e->term_counter, e->term_index, e->term_rows};
+               e->term_pool, e->term_counter, e->term_index, e->term_rows, e->aux_out};
     HIP_TRY(e, launch_step(e->G, e->padded_envs, e->consts, e->dev_consts, e->ptrs, a, (hipStream_t)stream));
     return UAVENV_OK;
 }
@@ -328,7 +329,7 @@ extern "C" int uavenv_rollout(UavEnv* e, int32_t num_steps, const int32_t* actio
     if (!e) return UAVENV_E_INVALID;
     if (num_steps <= 0) return fail(e, UAVENV_E_INVALID, "num_steps must be positive");
     StepArgs a{actions_dev, actions_out, obs, rew, rew32, done, term, e->num_envs,
-               e->term_pool, e->term_counter, nullptr, e->term_rows};   // per-step indices are not kept by rollouts
+               e->term_pool, e->term_counter, nullptr, e->term_rows, e->aux_out};   // aux [K][E][4] carries the pool rows
     HIP_TRY(e, launch_rollout(e->G, e->padded_envs, e->consts, e->dev_consts, e->ptrs, a, num_steps, (hipStream_t)stream));
     return UAVENV_OK;
 }
@@ -338,6 +339,12 @@ extern "C" int uavenv_set_terminal_pool(UavEnv* e, float* pool_dev, int32_t rows
     if (pool_dev != nullptr && (rows <= 0 || counter_dev == nullptr))
         return fail(e, UAVENV_E_INVALID, "terminal pool needs rows > 0 and a counter");
     e->term_pool = pool_dev; e->term_rows = rows; e->term_counter = counter_dev; e->term_index = index_out_dev;
+    return UAVENV_OK;
+}
+
+extern "C" int uavenv_set_aux_output(UavEnv* e, float* aux_out_dev) {
+    if (!e) return UAVENV_E_INVALID;
+    e->aux_out = aux_out_dev;
     return UAVENV_OK;
 }
 

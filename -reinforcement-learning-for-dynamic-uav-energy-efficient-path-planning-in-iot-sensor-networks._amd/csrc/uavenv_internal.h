@@ -78,6 +78,8 @@ struct StepArgs {
     uint32_t* term_counter;
     int32_t* term_index;
     int32_t term_rows;
+    float* aux;                 // optional float [E][4] = (action, reward, done, terminal-pool row or -1): the packed
+                                // remainder of a transition block, so that replay insertion needs no pack kernel
 };
 
 struct ResetArgs {

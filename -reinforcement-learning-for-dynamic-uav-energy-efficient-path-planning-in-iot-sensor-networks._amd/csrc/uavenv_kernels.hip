@@ -777,6 +777,7 @@ __device__ __forceinline__ void step_once(CRef c, const Ptrs& p, const StepArgs&
     // ---- observation of the stepped state (side effect: ADR EMA) -------------------------------
     const bool auto_reset = (c.flags & UAVENV_FLAG_AUTO_RESET) != 0;
     const bool do_reset = truncated & auto_reset;
+    int term_row = -1;
     {
         float* dst = nullptr;
         if (in_batch) {
@@ -792,6 +793,7 @@ __device__ __forceinline__ void step_once(CRef c, const Ptrs& p, const StepArgs&
                 if (do_reset & in_batch) { row = (int)t; dst = a.term_pool + (size_t)t * (size_t)c.obs_dim; }
             }
             if (in_batch && gl == 0 && a.term_index != nullptr) a.term_index[env] = row;
+            term_row = row;
         }
         observe<G>(c, s, n, e.gw, e.gh, e.ux, e.uy, e.battery, act, true, det, z.zD, z.zE, dst, lds_row);   // :488
     }
@@ -833,6 +835,8 @@ __device__ __forceinline__ void step_once(CRef c, const Ptrs& p, const StepArgs&
         if (a.reward) a.reward[env] = reward;
         if (a.reward32) a.reward32[env] = (float)reward;
         if (a.done) a.done[env] = truncated ? 1 : 0;
+        if (a.aux) reinterpret_cast<float4*>(a.aux)[env] = make_float4((float)action, (float)reward, truncated ? 1.0f : 0.0f,
+                                                                    (float)term_row);
     }
 
     // ---- SB3 VecEnv auto-reset: episode stats, reset, first observation of the new episode -----------
@@ -940,6 +944,7 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_rollout_
         if (a.reward32) ak.reward32 = a.reward32 + (size_t)k * E;
         if (a.done) ak.done = a.done + (size_t)k * E;
         if (a.term_index) ak.term_index = a.term_index + (size_t)k * E;
+        if (a.aux) ak.aux = a.aux + (size_t)k * E * 4;
         int action = 0;
         // Launder the constants pointer every iteration: otherwise LICM hoists all ~90 invariant scalar loads
         // out of the loop and the SGPR file spills into VGPR lanes (and those into scratch).

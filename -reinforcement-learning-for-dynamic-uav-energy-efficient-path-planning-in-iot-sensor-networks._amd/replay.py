@@ -1,12 +1,12 @@
-"""Shared replay ring fed by an all-gather of transition batches (BASELINE config 4).
+"""Shared replay ring fed by an all-gather of transition blocks (BASELINE config 4).
 
-One process per GPU owns a shard of environments.  Each vector step produces, per rank, a
-transition block  obs[E_local, D] float32 + aux[E_local, 4] float32 (action, reward, done, pad).
-The step kernel writes its observations DIRECTLY into this rank's slice of the ring slot
-(`slot_obs(slot)[rank]`), so inserting into the replay buffer costs no copy; the other ranks'
-slices arrive through one in-place `all_gather_into_tensor` per tensor (RCCL over xGMI when the
-backend is "nccl"; "gloo" on CPU for the multi-process tests).  The collective is issued on a side
-stream so that it overlaps the next environment step.
+One process per GPU owns a shard of environments.  Each vector step produces, per rank, ONE contiguous
+transition block   [ obs: E x D float32 | aux: E x 4 float32 = (action, reward, done, terminal row) ].
+The step kernel writes both parts DIRECTLY into this rank's block of the current ring slot
+(`local_obs_slot()` / `local_aux_slot()`, uavenv_set_aux_output), so inserting into the replay buffer
+costs no copy and no pack kernel; the other ranks' blocks arrive through one in-place
+`all_gather_into_tensor` per step (RCCL over xGMI when the backend is "nccl"; "gloo" on CPU for the
+multi-process tests), issued on a side stream so that it overlaps the next environment step.
 
 next_obs is not stored: it is the following slot's obs, except where `done` (the env was auto-reset,
 so the following slot holds the first observation of the NEXT episode): there the terminal observation
@@ -24,65 +24,68 @@ class TransitionRing:
         self.capacity, self.E, self.D = int(capacity), int(envs_per_rank), int(obs_dim)
         self.world, self.rank, self.group = int(world_size), int(rank), group
         self.device = torch.device(device)
-        # [slot][rank][env][...]: a rank's block is contiguous => in-place all-gather
-        self.obs = torch.zeros(self.capacity, self.world, self.E, self.D, dtype=torch.float32, device=self.device)
-        self.aux = torch.zeros(self.capacity, self.world, self.E, 4, dtype=torch.float32, device=self.device)
+        # [slot][rank][block]: a rank's block (obs then aux) is contiguous => ONE in-place all-gather per step
+        self.block = self.E * (self.D + 4)
+        self.store = torch.zeros(self.capacity, self.world, self.block, dtype=torch.float32, device=self.device)
+        self.obs = self.store[:, :, :self.E * self.D].view(self.capacity, self.world, self.E, self.D)
+        self.aux = self.store[:, :, self.E * self.D:].view(self.capacity, self.world, self.E, 4)
         # terminal-observation pool (rows recycle; sized so that a row outlives the ring slot that refers to it:
         # ~E/1400 episodes end per step)
         self.terminal_rows = int(terminal_rows) if terminal_rows is not None else max(1024, (self.capacity * self.E) // 256)
         self.term_pool = torch.zeros(self.terminal_rows, self.D, dtype=torch.float32, device=self.device)
         self.term_counter = torch.zeros(1, dtype=torch.int32, device=self.device)
-        self.term_index = torch.full((self.E,), -1, dtype=torch.int32, device=self.device)
-        self._attached = False
+        self._env = None
         self.head = 0                 # next slot to write
         self.size = 0                 # number of valid slots
         self._pending = [None] * self.capacity
         self._comm_stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
 
     def attach(self, env):
-        """Let `env` (BatchedUAVEnv) write terminal observations straight into this ring's pool."""
-        env.set_terminal_pool(self.term_pool, self.term_counter, self.term_index)
-        self._attached = True
+        """Let `env` (BatchedUAVEnv) write terminal observations into this ring's pool and the (action, reward,
+        done, terminal row) part of every transition straight into the ring."""
+        env.set_terminal_pool(self.term_pool, self.term_counter, None)
+        self._env = env
+        env.set_aux_output(self.local_aux_slot())
 
     # ---- producer side -----------------------------------------------------------------------
     def local_obs_slot(self, slot=None):
-        """[E, D] view of THIS rank's slice of a slot: pass it as `obs_out` to BatchedUAVEnv.step*()."""
+        """[E, D] view of THIS rank's part of a slot: pass it as `obs_out` to BatchedUAVEnv.step*()."""
         return self.obs[self.head if slot is None else slot, self.rank]
+
+    def local_aux_slot(self, slot=None):
+        return self.aux[self.head if slot is None else slot, self.rank]
 
     def wait_slot(self, slot):
         w = self._pending[slot]
         if w is not None:
-            for x in w:
-                x.wait()
+            w.wait()
             self._pending[slot] = None
 
-    def commit(self, actions, reward, done):
-        """Record (action, reward, done) of the step whose observations were written into
-        local_obs_slot(), then publish this rank's block of the slot to every rank."""
+    def commit(self, actions=None, reward=None, done=None):
+        """Publish this rank's block of the current slot.  With an attached env the kernel has already written
+        the aux part; otherwise (tests, foreign producers) pass actions / reward / done to fill it here."""
         slot = self.head
-        aux = self.aux[slot, self.rank]
-        aux[:, 0] = actions.to(torch.float32)
-        aux[:, 1] = reward.to(torch.float32)
-        aux[:, 2] = done.to(torch.float32)
-        aux[:, 3] = self.term_index.to(torch.float32) if self._attached else -1.0
+        if actions is not None:
+            aux = self.aux[slot, self.rank]
+            aux[:, 0] = actions.to(torch.float32)
+            aux[:, 1] = reward.to(torch.float32)
+            aux[:, 2] = done.to(torch.float32)
+            aux[:, 3] = -1.0
         if self.world > 1:
+            out, inp = self.store[slot].view(-1), self.store[slot, self.rank]
             if self._comm_stream is not None:
                 self._comm_stream.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(self._comm_stream):
-                    w1 = dist.all_gather_into_tensor(self.obs[slot].view(-1), self.obs[slot, self.rank].reshape(-1),
-                                                     group=self.group, async_op=True)
-                    w2 = dist.all_gather_into_tensor(self.aux[slot].view(-1), self.aux[slot, self.rank].reshape(-1),
-                                                     group=self.group, async_op=True)
-            else:   # CPU / gloo (tests): same calls, synchronous streams
-                w1 = dist.all_gather_into_tensor(self.obs[slot].view(-1), self.obs[slot, self.rank].reshape(-1).clone(),
-                                                 group=self.group, async_op=True)
-                w2 = dist.all_gather_into_tensor(self.aux[slot].view(-1), self.aux[slot, self.rank].reshape(-1).clone(),
-                                                 group=self.group, async_op=True)
-            self._pending[slot] = (w1, w2)
+                    w = dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
+            else:   # CPU / gloo (tests)
+                w = dist.all_gather_into_tensor(out, inp.clone(), group=self.group, async_op=True)
+            self._pending[slot] = w
         self.head = (slot + 1) % self.capacity
         self.size = min(self.size + 1, self.capacity)
         # the slot about to be overwritten next must have finished its previous gather
         self.wait_slot(self.head)
+        if self._env is not None:
+            self._env.set_aux_output(self.local_aux_slot())
         return slot
 
     def drain(self):
@@ -92,30 +95,33 @@ class TransitionRing:
             torch.cuda.current_stream(self.device).wait_stream(self._comm_stream)
 
     # ---- consumer side -----------------------------------------------------------------------
-    def sample(self, batch_size, generator=None):
-        """Uniform sample of transitions (obs, action, reward, done, next_obs) over all ranks' envs.
-        Only slots whose successor slot is valid are eligible (next_obs = successor's obs)."""
-        assert self.size >= 2
-        self.drain()
+    def _draw(self, batch_size, generator):
         n_slots = self.size - 1
-        newest = (self.head - 1) % self.capacity
         oldest = (self.head - self.size) % self.capacity
-        k = torch.randint(0, n_slots, (batch_size,), generator=generator, device=self.device)
-        slot = (oldest + k) % self.capacity
-        nxt = (slot + 1) % self.capacity
+        j = torch.randint(0, n_slots, (batch_size,), generator=generator, device=self.device)
         r = torch.randint(0, self.world, (batch_size,), generator=generator, device=self.device)
         e = torch.randint(0, self.E, (batch_size,), generator=generator, device=self.device)
-        aux = self.aux[slot, r, e]
-        assert newest != oldest or self.size == 1
+        return j, (oldest + j) % self.capacity, r, e
+
+    def _next_frame(self, slot, r, e):
+        """(action, reward, done, newest frame of next_obs, valid) of the transitions slot -> slot+1."""
+        nxt = (slot + 1) % self.capacity
+        aux = self.aux[nxt, r, e]                  # the aux row stored WITH an observation describes the step INTO it
         done = aux[:, 2] > 0.5
-        next_obs = self.obs[nxt, r, e]
         tidx = aux[:, 3].long()
         have_term = done & (tidx >= 0) & (r == self.rank)
-        next_obs = torch.where(have_term.unsqueeze(1), self.term_pool[tidx.clamp(min=0)], next_obs)
-        valid = ~done | have_term
-        return dict(obs=self.obs[slot, r, e], action=aux[:, 0].long(), reward=aux[:, 1], done=done,
-                    next_obs=next_obs, valid=valid)
+        last = torch.where(have_term.unsqueeze(1), self.term_pool[tidx.clamp(min=0)], self.obs[nxt, r, e])
+        return aux[:, 0].long(), aux[:, 1], done, last, ~done | have_term
 
+    def sample(self, batch_size, generator=None):
+        """Uniform sample of transitions (obs, action, reward, done, next_obs, valid) over all ranks' envs.
+        Slot s holds the observation s_t together with (a, r, done) of the step that PRODUCED it, so the
+        transition out of slot s reads its action / reward / done from slot s+1."""
+        assert self.size >= 2
+        self.drain()
+        _, slot, r, e = self._draw(batch_size, generator)
+        action, reward, done, last, valid = self._next_frame(slot, r, e)
+        return dict(obs=self.obs[slot, r, e], action=action, reward=reward, done=done, next_obs=last, valid=valid)
 
     def sample_stacked(self, batch_size, n_stack, generator=None):
         """Like sample(), but observations are frame stacks of `n_stack` frames gathered from the ring on the
@@ -125,12 +131,7 @@ class TransitionRing:
         assert self.size >= n_stack + 1
         self.drain()
         k = int(n_stack)
-        n_slots = self.size - 1
-        oldest = (self.head - self.size) % self.capacity
-        j = torch.randint(0, n_slots, (batch_size,), generator=generator, device=self.device)
-        slot = (oldest + j) % self.capacity
-        r = torch.randint(0, self.world, (batch_size,), generator=generator, device=self.device)
-        e = torch.randint(0, self.E, (batch_size,), generator=generator, device=self.device)
+        j, slot, r, e = self._draw(batch_size, generator)
         back = torch.arange(k - 1, -1, -1, device=self.device)                      # k-1 ... 0 (oldest first)
         fs = (slot.unsqueeze(1) - back.unsqueeze(0)) % self.capacity                # [B, k] frame slots
         in_ring = (j.unsqueeze(1) - back.unsqueeze(0)) >= 0                         # frame older than the ring start?
@@ -141,14 +142,8 @@ class TransitionRing:
         later_start = torch.flip(torch.cumsum(torch.flip(dn[:, 1:], [1]).int(), 1), [1]) > 0     # [B, k-1]
         valid_f = torch.cat([~later_start, torch.ones(batch_size, 1, dtype=torch.bool, device=self.device)], 1) & in_ring
         frames = frames * valid_f.unsqueeze(2)
-        obs = frames.reshape(batch_size, k * self.D)
-        nxt = (slot + 1) % self.capacity
-        aux = self.aux[nxt, r, e]                  # (action, reward, done) OF the transition slot -> nxt
-        done = aux[:, 2] > 0.5
-        tidx = aux[:, 3].long()
-        have_term = done & (tidx >= 0) & (r == self.rank)
-        last = torch.where(have_term.unsqueeze(1), self.term_pool[tidx.clamp(min=0)], self.obs[nxt, r, e])
+        action, reward, done, last, valid = self._next_frame(slot, r, e)
         # next stack = [frames 1..k-1 | newest]; after an auto-reset the real next state is the terminal observation
         next_obs = torch.cat([frames[:, 1:].reshape(batch_size, (k - 1) * self.D), last], 1)
-        return dict(obs=obs, action=aux[:, 0].long(), reward=aux[:, 1], done=done, next_obs=next_obs,
-                    valid=~done | have_term)
+        return dict(obs=frames.reshape(batch_size, k * self.D), action=action, reward=reward, done=done,
+                    next_obs=next_obs, valid=valid)

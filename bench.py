@@ -114,16 +114,14 @@ def main():
     exchange = args.exchange
     if exchange == "auto":
         exchange = "allgather" if distributed else "none"
-    ring = TransitionRing(args.ring, E, env.obs_dim, dev, world_size=world, rank=rank)
+    ring = TransitionRing(args.ring, E, env.obs_dim, dev, world_size=world if exchange == "allgather" else 1,
+                          rank=rank if exchange == "allgather" else 0)
+    ring.attach(env)      # the kernel writes obs AND (action, reward, done, terminal row) straight into the ring slot
     env.reset()
 
     def one_step():
-        # the kernel writes the observations straight into this rank's slice of the ring slot
-        obs, rew, done = env.step_random(obs_out=ring.local_obs_slot())
-        if exchange == "allgather":
-            ring.commit(env.actions_taken, env.reward32, done)
-        else:
-            ring.head = (ring.head + 1) % ring.capacity
+        env.step_random(obs_out=ring.local_obs_slot())
+        ring.commit()     # N > 1: one in-place RCCL all-gather of this rank's transition block, on a side stream
 
     def barrier():
         if distributed:

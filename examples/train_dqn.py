@@ -117,7 +117,7 @@ def main():
         rnd = torch.randint(0, 5, (E,), device=dev, dtype=torch.int32)
         actions = torch.where(torch.rand(E, device=dev) < eps, rnd, greedy)
         o, r, d = env.step(actions, obs_out=ring.local_obs_slot())
-        ring.commit(actions, env.reward32, d)
+        ring.commit()
         stacked = fs.step(o, d, None)
         if step >= args.learning_starts and step % args.train_freq == 0:
             for _ in range(args.updates):

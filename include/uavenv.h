@@ -210,6 +210,12 @@ int uavenv_rollout(UavEnv* env, int32_t num_steps, const int32_t* actions_dev, i
  * pool_dev == NULL restores the per-env terminal_obs_dev rows. */
 int uavenv_set_terminal_pool(UavEnv* env, float* pool_dev, int32_t rows, uint32_t* counter_dev, int32_t* index_out_dev);
 
+/* Optional packed remainder of the transition block: when set, every step also writes
+ * aux_out_dev float [E][4] = (action, reward, done, terminal-pool row or -1) -- with obs_out_dev this is the whole
+ * (obs, action, reward, done) transition, so inserting into a replay buffer needs no extra pack kernel and the
+ * multi-GPU exchange is one all-gather of one contiguous block.  (uavenv_rollout: [K][E][4].)  NULL disables. */
+int uavenv_set_aux_output(UavEnv* env, float* aux_out_dev);
+
 /* ---- frame stack (the caller directly above the path in the trainer: dqn.py:1278) ------------------ */
 /* replaces: SB3 VecFrameStack(n_stack=k).step_wait on device, in place.  stacked_dev float [E][k*obs_dim]
  * (oldest frame first) is shifted left by one frame and obs_dev [E][obs_dim] appended; where done_dev[e]

@@ -222,8 +222,8 @@ def test_replay_ring_with_terminal_pool():
     env.reset(); ring.local_obs_slot().copy_(env.obs)
     ring.commit(torch.zeros(E, device=env.device), torch.zeros(E, device=env.device), torch.zeros(E, device=env.device))
     for s in range(steps):
-        _, _, done = env.step_random(obs_out=ring.local_obs_slot())
-        ring.commit(env.actions_taken, env.reward32, done)
+        env.step_random(obs_out=ring.local_obs_slot())
+        ring.commit()                                  # the kernel wrote (action, reward, done, pool row) itself
     torch.cuda.synchronize()
     # slot s+1 holds obs after step s together with (action, reward, done) OF step s
     obs = ring.obs[:, 0].cpu().numpy(); aux = ring.aux[:, 0].cpu().numpy(); pool = ring.term_pool.cpu().numpy()
@@ -254,9 +254,9 @@ def test_stacked_sampling_equals_frame_stack():
     stacks = [fs.reset(obs).clone()]; terms = [None]
     for s in range(steps):
         o, r, d = env.step_random(obs_out=ring.local_obs_slot())
-        ring.commit(env.actions_taken, env.reward32, d)
+        ring.commit()
         # (with the pool attached the kernel writes terminal rows into ring.term_pool, not env.terminal_obs)
-        stacks.append(fs.step(o, d, None).clone()); terms.append((d.clone(), ring.term_index.clone()))
+        stacks.append(fs.step(o, d, None).clone()); terms.append((d.clone(), ring.aux[ring.head - 1, 0, :, 3].clone()))
     g = torch.Generator(device=env.device).manual_seed(0)
     b = ring.sample_stacked(4096, k, generator=g)
     g = torch.Generator(device=env.device).manual_seed(0)          # replay the index draws

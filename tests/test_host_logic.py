@@ -66,7 +66,7 @@ def test_transition_ring_single_rank_cpu():
     b = ring.sample(64, generator=torch.Generator().manual_seed(0))
     assert b["obs"].shape == (64, 5) and b["next_obs"].shape == (64, 5)
     assert torch.all(b["next_obs"][:, 0] == b["obs"][:, 0] + 1)         # successor slot = next step
-    assert torch.equal(b["reward"], b["obs"][:, 0] * 10.0)
+    assert torch.equal(b["reward"], b["next_obs"][:, 0] * 10.0)         # (a, r, done) are stored with the obs they produced
     # done transitions without a pool entry are flagged invalid (next_obs would be the next episode's first obs)
     assert torch.equal(b["valid"], ~b["done"])
     ring.term_pool[5] = 77.0
