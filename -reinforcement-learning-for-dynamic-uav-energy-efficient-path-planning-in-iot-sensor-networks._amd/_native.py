@@ -54,7 +54,7 @@ def record_dtype():
         ("current_step", "<i4"), ("episode", "<u4"), ("capture_triggers", "<i4"), ("boundary_hits", "<i4"),
         ("edge_steps", "<i4"), ("collisions_total", "<i4"), ("first_full_coverage_step", "<i4"),
         ("grid_w", "<i4"), ("grid_h", "<i4"), ("num_sensors", "<i4"), ("env_index", "<u4"), ("status", "<u4"),
-        ("reserved", "<u4", (4,)),
+        ("inv_grid_w", "<f8"), ("inv_grid_h", "<f8"),
     ])
 
 

@@ -109,6 +109,8 @@ static void derive_consts(const UavEnvConfig& c, Consts& k) {
     std::memset(&k, 0, sizeof(k));
     k.seed = c.seed;
     k.rate = c.data_generation_rate; k.bmax = c.max_buffer_size; k.thr = c.rssi_threshold;
+    k.inv_bmax = 1.0 / c.max_buffer_size; k.inv_maxb = 1.0 / c.max_battery;
+    k.inv_rate = c.data_generation_rate > 0 ? 1.0 / c.data_generation_rate : 0.0;
     k.p_cycle = c.duty_cycle / 100.0;                                    // iot_sensors.py:105-107
     k.maxb = c.max_battery; k.coll_dur = c.collection_duration;
     k.sigma = c.shadowing_std_db; k.lambda = c.adr_lambda; k.one_minus_lambda = 1 - c.adr_lambda;
@@ -173,6 +175,7 @@ extern "C" int uavenv_create(const UavEnvConfig* cfg, int32_t num_envs, uint32_t
     if (num_envs <= 0) return fail(nullptr, UAVENV_E_INVALID, "num_envs must be positive");
     if (cfg->num_sensors < 1 || cfg->num_sensors > 64) return fail(nullptr, UAVENV_E_INVALID, "num_sensors must be in 1..64");
     if (cfg->grid_w < 1 || cfg->grid_h < 1) return fail(nullptr, UAVENV_E_INVALID, "grid must be positive");
+    if (!(cfg->max_buffer_size > 0) || !(cfg->max_battery > 0)) return fail(nullptr, UAVENV_E_INVALID, "max_buffer_size and max_battery must be positive");
     if (cfg->num_grid_choices < 0 || cfg->num_grid_choices > 8) return fail(nullptr, UAVENV_E_INVALID, "num_grid_choices must be in 0..8");
     static_assert(sizeof(UavEnvRecord) == 128, "UavEnvRecord must be 128 bytes");
     UavEnv* e = new (std::nothrow) UavEnv();
@@ -241,8 +244,8 @@ extern "C" int uavenv_set_env_params(UavEnv* e, const int32_t* gw, const int32_t
     std::vector<UavEnvRecord> recs((size_t)e->num_envs);
     HIP_TRY(e, hipMemcpy(recs.data(), e->ptrs.rec, recs.size() * sizeof(UavEnvRecord), hipMemcpyDeviceToHost));
     for (int i = 0; i < e->num_envs; i++) {
-        if (gw) { if (gw[i] < 1) return fail(e, UAVENV_E_INVALID, "grid_w must be positive"); recs[i].grid_w = gw[i]; }
-        if (gh) { if (gh[i] < 1) return fail(e, UAVENV_E_INVALID, "grid_h must be positive"); recs[i].grid_h = gh[i]; }
+        if (gw) { if (gw[i] < 1) return fail(e, UAVENV_E_INVALID, "grid_w must be positive"); recs[i].grid_w = gw[i]; recs[i].inv_grid_w = 1.0 / gw[i]; }
+        if (gh) { if (gh[i] < 1) return fail(e, UAVENV_E_INVALID, "grid_h must be positive"); recs[i].grid_h = gh[i]; recs[i].inv_grid_h = 1.0 / gh[i]; }
         if (ns) {
             if (ns[i] < 1 || ns[i] > e->cfg.num_sensors) return fail(e, UAVENV_E_INVALID, "per-env num_sensors must be in 1..cfg.num_sensors");
             recs[i].num_sensors = ns[i];

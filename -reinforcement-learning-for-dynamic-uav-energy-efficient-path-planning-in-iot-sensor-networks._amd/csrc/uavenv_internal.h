@@ -21,6 +21,7 @@ struct Consts {
     // ---- every step ------------------------------------------------------------------------
     uint64_t seed;
     double rate, bmax, thr;
+    double inv_bmax, inv_maxb, inv_rate;   // correctly rounded reciprocals for div_const() (0 if the divisor is 0)
     double sigma, lambda, one_minus_lambda, tx_power;
     double d_break;        // iot_sensors.py:174  (4*pi*ht*hr)/0.345
     double c_fs;           // iot_sensors.py:179  20*log10(868)

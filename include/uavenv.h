@@ -99,7 +99,7 @@ typedef struct UavEnvRecord {
     int32_t grid_w, grid_h, num_sensors;
     uint32_t env_index;            /* GLOBAL environment index (Philox counter word 0)    */
     uint32_t status;               /* bit 0: an invalid action was seen                   */
-    uint32_t reserved[4];
+    double  inv_grid_w, inv_grid_h;/* 1/grid_w, 1/grid_h (kept by the library: lets the kernel divide by multiplying) */
 } UavEnvRecord;
 
 /* Written once per finished episode when UAVENV_FLAG_AUTO_RESET is set (what DomainRandEnv.reset

@@ -63,3 +63,26 @@ conc = np.cumsum(ev[:, 1])
 for t_us in (0.5, 1, 2, 4, 6, 8, 10, 12, 14, 16):
     i = np.searchsorted(ev[:, 0], t_us * 100)
     print("  t=%5.1f us  resident waves %d" % (t_us, conc[min(i, len(conc) - 1)]))
+
+# per-SIMD composition: does the launch tail come from SIMDs that host several collect-action waves?
+wave_in_cu = (hw >> 0) & 0xF
+skey = key * 4 + simd.astype(np.int64)
+import collections
+by = collections.defaultdict(list)
+for i in range(nw):
+    by[int(skey[i])].append(i)
+rows = []
+for kx, idxs in by.items():
+    nc = int(sum(act[i] == 4 for i in idxs))
+    rows.append((nc, len(idxs), max((r1[i] - T0) / 100 for i in idxs), np.mean([life[i] for i in idxs])))
+rows = np.array(rows)
+print("SIMDs", len(rows), "waves/SIMD min %d max %d" % (rows[:, 1].min(), rows[:, 1].max()))
+for nc in range(5):
+    m = rows[:, 0] == nc
+    if m.any():
+        print("  SIMDs with %d collect waves: %4d   finish time us: mean %.2f max %.2f   mean wave life %.0f cycles" %
+              (nc, m.sum(), rows[m, 2].mean(), rows[m, 2].max(), rows[m, 3].mean()))
+late = np.argsort(r1)[-12:]
+for i in late:
+    print("  late wave: end %.2f us life %d cycles action %d  simd-collects %d" %
+          ((r1[i] - T0) / 100, life[i], act[i], sum(act[j] == 4 for j in by[int(skey[i])])))
