@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(HERE, "liborc.so")
 MAX_SENSORS = 64
 
 FLAG_RANDOM_LAYOUT, FLAG_FAR_START, FLAG_PROX_SHAPING, FLAG_JAIN_BONUS = 1, 2, 4, 8
+POLICY_NEAREST, POLICY_MAX_THROUGHPUT_V2 = 2, 3
 
 _D = C.c_double
 
@@ -99,7 +100,13 @@ def lib():
         L.orc_normal_pair.argtypes = [C.c_uint32, C.c_uint32, fp, fp]
         L.orc_run_random_policy.argtypes = [C.POINTER(OrcConfig), C.c_int, C.c_uint32, C.c_int, C.POINTER(_D)]
         L.orc_run_random_policy.restype = C.c_long
-        L.orc_trace_keyed.argtypes = [C.POINTER(OrcConfig), C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_int,
+        L.orc_policy_action.argtypes = [C.POINTER(OrcEnv), C.c_int, fp]
+        L.orc_policy_action.restype = C.c_int
+        L.orc_step_policy_tape.argtypes = [C.POINTER(OrcEnv), C.c_int, fp, fp, C.POINTER(_D), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_step_policy_tape.restype = C.c_int
+        L.orc_step_policy_keyed.argtypes = [C.POINTER(OrcEnv), C.c_int, fp, C.POINTER(_D), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_step_policy_keyed.restype = C.c_int
+        L.orc_trace_keyed.argtypes = [C.POINTER(OrcConfig), C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_trace_keyed.restype = C.c_long
         L.orc_rssi_deterministic.argtypes = [C.POINTER(OrcConfig), C.c_float, C.c_float, C.c_float, C.c_float]
@@ -160,8 +167,16 @@ class OracleEnv:
         self.L.orc_reset_tape(C.byref(self.e), _fp(rt), _fp(obs))
         return obs
 
+    def step_policy_tape(self, policy, tp):
+        """tp float32[7, n] incl. the zP row; returns (action, obs, reward, truncated)."""
+        tp = np.ascontiguousarray(tp, np.float32); assert tp.shape == (7, self.n)
+        obs = np.empty(self.obs_dim, np.float32)
+        r = _D(); tr = C.c_int(); a = C.c_int()
+        self.L.orc_step_policy_tape(C.byref(self.e), int(policy), _fp(tp), _fp(obs), C.byref(r), C.byref(tr), C.byref(a))
+        return a.value, obs, r.value, bool(tr.value)
+
     def step_tape(self, action, tp):
-        tp = np.ascontiguousarray(tp, np.float32); assert tp.shape == (6, self.n)
+        tp = np.ascontiguousarray(np.asarray(tp)[:6], np.float32); assert tp.shape == (6, self.n)
         obs = np.empty(self.obs_dim, np.float32)
         r = _D(); tr = C.c_int()
         rc = self.L.orc_step_tape(C.byref(self.e), int(action), _fp(tp), _fp(obs), C.byref(r), C.byref(tr))
@@ -239,7 +254,7 @@ def _env_state(e, n):
                 start_x=np.float32(e.start_x), start_y=np.float32(e.start_y))
 
 
-def trace_keyed(cfg, num_envs, steps, base=0, actions=None, auto_reset=True):
+def trace_keyed(cfg, num_envs, steps, base=0, actions=None, auto_reset=True, policy=0):
     """Run the keyed oracle for a batch; returns dict(obs[steps,E,D], reward, done, term_obs, actions,
     reset_obs[E,D], final=[per-env state dicts])."""
     L = lib()
@@ -254,7 +269,7 @@ def trace_keyed(cfg, num_envs, steps, base=0, actions=None, auto_reset=True):
         actions = np.ascontiguousarray(actions, np.int32); assert actions.shape == (steps, E)
         ap = actions.ctypes.data_as(C.c_void_p)
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
-    L.orc_trace_keyed(C.byref(cfg), E, base, steps, ap, int(auto_reset), vp(obs), vp(rew), vp(done), vp(term),
+    L.orc_trace_keyed(C.byref(cfg), E, base, steps, ap, int(policy), int(auto_reset), vp(obs), vp(rew), vp(done), vp(term),
                       vp(acts_out), vp(reset_obs), C.cast(finals, C.c_void_p))
     return dict(obs=obs, reward=rew, done=done, term_obs=term, actions=acts_out, reset_obs=reset_obs,
                 final=[_env_state(finals[i], cfg.num_sensors) for i in range(E)])

@@ -647,7 +647,8 @@ void orc_normal_pair(uint32_t a, uint32_t b, float* z0, float* z1) {
  *   call 1 (collect steps):                               w0,w1 -> (zA,zB); w2,w3 -> (zC,-)
  *   call 2 (reset, step 0): w0 -> u_fill; w1,w2 -> layout x,y; lane 0's w3 -> curriculum grid choice
  *   call 3 (lane 0):        w0 -> random-policy action
- *   call 4 (lane = try):    w0,w1 -> far-start candidate */
+ *   call 4 (lane = try):    w0,w1 -> far-start candidate
+ *   call 5 (policy steps):  w0,w1 -> (zP, -) in-range sample drawn by a heuristic policy before the step */
 static void noise_words(uint64_t seed, uint32_t env, uint32_t ep, uint32_t step, uint32_t lane,
                         uint32_t call, uint32_t w[4]) {
     uint32_t ctr[4] = {env, ep, step, lane | (call << 16)};
@@ -659,6 +660,8 @@ static inline float u24(uint32_t w) { return (float)(w >> 8) * 0x1p-24f; }
 void orc_noise_step_tape(uint64_t seed, uint32_t env, uint32_t ep, uint32_t step, int n, float* tp) {
     for (int i = 0; i < n; i++) {
         uint32_t w[4]; float a, b;
+        noise_words(seed, env, ep, step, (uint32_t)i, 5, w);
+        orc_normal_pair(w[0], w[1], &a, &b); tp[6 * n + i] = a;
         noise_words(seed, env, ep, step, (uint32_t)i, 1, w);
         orc_normal_pair(w[0], w[1], &a, &b); tp[0 * n + i] = a; tp[1 * n + i] = b;
         orc_normal_pair(w[2], w[3], &a, &b); tp[3 * n + i] = a;
@@ -736,9 +739,93 @@ void orc_reset_keyed(OrcEnv* e, float* obs_out) {
 }
 
 int orc_step_keyed(OrcEnv* e, int action, float* obs_out, double* reward_out, int* truncated_out) {
-    float tp[6 * ORC_MAX_SENSORS];
+    float tp[7 * ORC_MAX_SENSORS];
     orc_noise_step_tape(e->cfg.seed, e->env_index, e->episode, (uint32_t)(e->current_step + 1), e->n, tp);
     return orc_step_tape(e, action, tp, obs_out, reward_out, truncated_out);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Heuristic policies (agents/dqn/dqn_evaluation_results/greedy_agents.py)                      */
+/* ------------------------------------------------------------------------------------------ */
+
+/* greedy_agents.py:42-67 GreedyAgent._move_toward (float32 position arithmetic) */
+static int policy_move_toward(const OrcEnv* e, float tx, float ty) {
+    float dx = tx - e->uav_x, dy = ty - e->uav_y;
+    if (fabsf(dx) <= 0.5f && fabsf(dy) <= 0.5f) return 4;
+    float nx = e->uav_x, ny = e->uav_y;
+    if (fabsf(dx) > fabsf(dy)) nx = e->uav_x + (dx > 0 ? 1.0f : -1.0f);
+    else ny = e->uav_y + (dy > 0 ? 1.0f : -1.0f);
+    if (nx < 0 || nx >= (float)e->grid_w || ny < 0 || ny >= (float)e->grid_h) return 4;
+    float mdx = nx - e->uav_x, mdy = ny - e->uav_y;
+    if (mdx > 0) return 3;
+    if (mdx < 0) return 2;
+    if (mdy > 0) return 0;
+    if (mdy < 0) return 1;
+    return 4;
+}
+static float policy_dist(const OrcEnv* e, int i) {          /* np.linalg.norm on float32 2-vectors */
+    float dx = e->pos_x[i] - e->uav_x, dy = e->pos_y[i] - e->uav_y;
+    return sqrtf(dx * dx + dy * dy);
+}
+
+/* Action chosen by a heuristic policy for the CURRENT state; zP[i] is the shadowing sample of the
+ * is_in_range() call the policy makes on sensor i (iot_sensors.py:214-219).
+ *   ORC_POLICY_NEAREST            greedy_agents.py:73-100  NearestSensorGreedy
+ *   ORC_POLICY_MAX_THROUGHPUT_V2  greedy_agents.py:105-216 MaxThroughputGreedyV2 */
+int orc_policy_action(const OrcEnv* e, int policy, const float* zP) {
+    const OrcConfig* c = &e->cfg;
+    int n = e->n;
+    if (policy == ORC_POLICY_NEAREST) {
+        for (int i = 0; i < n; i++)                                   /* :84-86 */
+            if (e->buffer[i] > 0 && sensor_rssi(e, i, (double)zP[i]) >= c->rssi_threshold) return 4;
+        int best = -1; float bd = 0.0f;                                /* :94-100 min() keeps the first minimum */
+        for (int i = 0; i < n; i++) {
+            if (!(e->buffer[i] > 0)) continue;
+            float d = policy_dist(e, i);
+            if (best < 0 || d < bd) { best = i; bd = d; }
+        }
+        if (best < 0) return 4;
+        return policy_move_toward(e, e->pos_x[best], e->pos_y[best]);
+    }
+    /* MaxThroughputGreedyV2.select_action :131-160 */
+    double battery_pct = e->battery / 274.0;                           /* :133 (hard-coded capacity) */
+    int steps_left = c->max_steps - e->current_step;                   /* :134 */
+    double r = (double)steps_left / (double)c->max_steps;
+    double steps_ratio = r < 1.0 ? r : 1.0;                            /* :207-208 */
+    int sf_threshold = (battery_pct > 0.5 && steps_ratio > 0.5) ? 9 : ((battery_pct > 0.2 && steps_ratio > 0.2) ? 10 : 12);
+    for (int i = 0; i < n; i++)                                        /* :139-144: any immediate candidate -> COLLECT */
+        if (e->buffer[i] > 0 && sensor_rssi(e, i, (double)zP[i]) >= c->rssi_threshold && e->sf[i] <= sf_threshold) return 4;
+    double sf_w;                                                       /* :164-169 */
+    if (battery_pct < 0.1 || steps_left < 50) sf_w = 1.0;
+    else if (battery_pct < 0.3 || steps_left < 150) sf_w = 2.0;
+    else sf_w = 5.0;
+    double best_score = -INFINITY; int best = -1;
+    for (int i = 0; i < n; i++) {                                      /* :174-190 */
+        if (e->buffer[i] <= 0) continue;
+        float distance = policy_dist(e, i);
+        int pr = 13 - e->sf[i]; if (pr < 0) pr = 0;
+        double sf_score = pr * 5.0 * sf_w;
+        double buffer_score = (e->buffer[i] / c->max_buffer_size) * 10.0;
+        double duty_score = (c->duty_cycle / 100.0) * 2.0;
+        float distance_penalty = ((distance / (float)e->grid_w) * 5.0f) * 1.0f;        /* float32 chain */
+        double score = ((sf_score + buffer_score) + duty_score) - (double)distance_penalty;
+        if (score > best_score) { best_score = score; best = i; }
+    }
+    if (best < 0) return 4;
+    return policy_move_toward(e, e->pos_x[best], e->pos_y[best]);
+}
+
+int orc_step_policy_tape(OrcEnv* e, int policy, const float* tp7, float* obs_out, double* reward_out, int* truncated_out,
+                         int* action_out) {
+    int a = orc_policy_action(e, policy, tp7 + 6 * e->n);
+    if (action_out) *action_out = a;
+    return orc_step_tape(e, a, tp7, obs_out, reward_out, truncated_out);
+}
+
+int orc_step_policy_keyed(OrcEnv* e, int policy, float* obs_out, double* reward_out, int* truncated_out, int* action_out) {
+    float tp[7 * ORC_MAX_SENSORS];
+    orc_noise_step_tape(e->cfg.seed, e->env_index, e->episode, (uint32_t)(e->current_step + 1), e->n, tp);
+    return orc_step_policy_tape(e, policy, tp, obs_out, reward_out, truncated_out, action_out);
 }
 
 /* cpu_baseline leg: E envs, random policy, auto-reset (what SB3's DummyVecEnv does around the
@@ -775,7 +862,7 @@ long orc_run_random_policy(const OrcConfig* c, int num_envs, uint32_t env_index_
  * (global indices base..base+num_envs-1), actions given ([steps][E]) or drawn by the random policy,
  * with SB3-style auto-reset when `auto_reset` (the step's own observation goes to term_out, the
  * reset observation to obs_out).  Any output pointer may be NULL.  final_envs: OrcEnv[num_envs]. */
-long orc_trace_keyed(const OrcConfig* c, int num_envs, uint32_t base, int steps, const int32_t* actions,
+long orc_trace_keyed(const OrcConfig* c, int num_envs, uint32_t base, int steps, const int32_t* actions, int policy,
                      int auto_reset, float* obs_out, double* rew_out, uint8_t* done_out, float* term_out,
                      int32_t* actions_out, float* reset_obs_out, OrcEnv* final_envs) {
     OrcEnv* envs = (OrcEnv*)malloc(sizeof(OrcEnv) * (size_t)num_envs);
@@ -794,10 +881,14 @@ long orc_trace_keyed(const OrcConfig* c, int num_envs, uint32_t base, int steps,
         for (int k = 0; k < num_envs; k++) {
             OrcEnv* e = &envs[k];
             size_t row = (size_t)s * (size_t)num_envs + (size_t)k;
-            int a = actions ? actions[row]
-                            : orc_noise_action(c->seed, e->env_index, e->episode, (uint32_t)(e->current_step + 1));
+            int a;
             double r = 0.0; int tr = 0;
-            orc_step_keyed(e, a, obs, &r, &tr);
+            if (policy >= 2) orc_step_policy_keyed(e, policy, obs, &r, &tr, &a);
+            else {
+                a = actions ? actions[row]
+                            : orc_noise_action(c->seed, e->env_index, e->episode, (uint32_t)(e->current_step + 1));
+                orc_step_keyed(e, a, obs, &r, &tr);
+            }
             count++;
             if (actions_out) actions_out[row] = a;
             if (rew_out) rew_out[row] = r;

@@ -62,6 +62,9 @@ typedef struct OrcConfig {
 
 #define ORC_MAX_SENSORS 64
 
+#define ORC_POLICY_NEAREST            2   /* greedy_agents.py:73  NearestSensorGreedy   */
+#define ORC_POLICY_MAX_THROUGHPUT_V2  3   /* greedy_agents.py:105 MaxThroughputGreedyV2 */
+
 /* One environment instance; plain data so tests can poke it through ctypes. */
 typedef struct OrcEnv {
     OrcConfig cfg;
@@ -96,7 +99,7 @@ int  orc_step_tape(OrcEnv* e, int action, const float* step_tape, float* obs_out
 
 /* Keyed entry points: the tape is generated by the counter-based noise specification shared with
  * the HIP kernel (Philox4x32-10 + transcendental-free Box-Muller, DESIGN.md "Noise"). */
-void orc_noise_step_tape(uint64_t seed, uint32_t env_index, uint32_t episode, uint32_t step, int n, float* tape6);
+void orc_noise_step_tape(uint64_t seed, uint32_t env_index, uint32_t episode, uint32_t step, int n, float* tape7);
 void orc_noise_reset_tape(uint64_t seed, uint32_t env_index, uint32_t episode, int n, float* tape3);
 void orc_noise_positions(uint64_t seed, uint32_t env_index, uint32_t episode, int n, int w, int h, float* px, float* py);
 int  orc_noise_action(uint64_t seed, uint32_t env_index, uint32_t episode, uint32_t step);
@@ -111,7 +114,11 @@ int  orc_step_keyed(OrcEnv* e, int action, float* obs_out, double* reward_out, i
 long orc_run_random_policy(const OrcConfig* c, int num_envs, uint32_t env_index_base, int steps,
                            double* reward_checksum);
 
-long orc_trace_keyed(const OrcConfig* c, int num_envs, uint32_t base, int steps, const int32_t* actions,
+int  orc_policy_action(const OrcEnv* e, int policy, const float* zP);
+int  orc_step_policy_tape(OrcEnv* e, int policy, const float* step_tape7, float* obs_out, double* reward_out,
+                          int* truncated_out, int* action_out);
+int  orc_step_policy_keyed(OrcEnv* e, int policy, float* obs_out, double* reward_out, int* truncated_out, int* action_out);
+long orc_trace_keyed(const OrcConfig* c, int num_envs, uint32_t base, int steps, const int32_t* actions, int policy,
                      int auto_reset, float* obs_out, double* rew_out, uint8_t* done_out, float* term_out,
                      int32_t* actions_out, float* reset_obs_out, OrcEnv* final_envs);
 

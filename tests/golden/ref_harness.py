@@ -13,7 +13,8 @@ Injection points (all process-local monkey patches, restored on exit):
         calculate_rssi <- get_success_probability(use_advanced_model=True)     => zB
         calculate_rssi <- get_success_probability(False) <- collect_data       => zC
         calculate_rssi <- update_spreading_factor <- _get_observation          => zD
-        calculate_rssi <- is_in_range                                          => zE
+        calculate_rssi <- is_in_range <- _get_observation                      => zE
+        calculate_rssi <- is_in_range <- (a greedy agent's select_action)      => zP
   * `uav_env.random`           -> object whose .random() returns the lottery uniform of the sensor
                                   currently iterated at uav_env.py:535-551
   * `env.np_random`            -> object whose .uniform(lo, hi) returns lo + (hi-lo)*u_fill[k] for
@@ -91,7 +92,7 @@ class TapedReference:
         elif name1 == "get_success_probability":
             slot = T.SLOT_ZB if c1.f_locals["use_advanced_model"] else T.SLOT_ZC
         elif name1 == "is_in_range":
-            slot = T.SLOT_ZE
+            slot = T.SLOT_ZE if c1.f_back.f_code.co_name == "_get_observation" else T.SLOT_ZP
         else:
             raise AssertionError(name1)
         ts = self.ts
@@ -155,6 +156,23 @@ class TapedReference:
         ts.used = np.zeros((T.NUM_STEP_SLOTS, self.n), dtype=bool)
         self.vstep += 1
         return self.env.step(int(action))
+
+    def make_agent(self, kind):
+        """The reference's own heuristic agents (agents/dqn/dqn_evaluation_results/greedy_agents.py)."""
+        d = os.path.join(REF_SRC, "agents", "dqn", "dqn_evaluation_results")
+        if d not in sys.path:
+            sys.path.insert(0, d)
+        import greedy_agents as GA
+        return {"nearest": GA.NearestSensorGreedy, "max_throughput_v2": GA.MaxThroughputGreedyV2}[kind](self.env)
+
+    def policy_step(self, agent, obs):
+        """select_action (consumes zP samples of THIS step's tape) followed by step(action)."""
+        ts = self.ts
+        ts.step = T.step_tape(self.tape_seed, self.env_index, self.vstep, self.n)
+        ts.used = np.zeros((T.NUM_STEP_SLOTS, self.n), dtype=bool)
+        action = int(agent.select_action(obs))
+        self.vstep += 1
+        return action, self.env.step(action)
 
     def state(self):
         """Full per-sensor / per-env state as plain arrays (float64 where the reference holds Python floats)."""

@@ -9,7 +9,14 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def fixture_names():
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+    """Environment fixtures (make_golden.py)."""
+    return sorted(n for n in (os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+                  if not n.startswith("policy_"))
+
+
+def policy_fixture_names():
+    """Heuristic-policy fixtures (make_golden_policies.py)."""
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "policy_*.npz")))
 
 
 def load(name):

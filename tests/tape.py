@@ -9,6 +9,7 @@ reference draws, per sensor and per step, up to five standard normals and one un
     slot 3  zC  collect_data range check      (iot_sensors.py:131 via uav_env.py:581)
     slot 4  zD  observation ADR sample        (iot_sensors.py:234 via uav_env.py:654)
     slot 5  zE  observation in-range check    (iot_sensors.py:215 via uav_env.py:658)
+    slot 6  zP  in-range check made by a heuristic policy BEFORE the step (greedy_agents.py:85, :139)
 
 plus, per reset: the buffer pre-fill uniform (uav_env.py:410) and the (zD, zE) pair consumed by
 the observation built inside reset() (uav_env.py:427).
@@ -21,8 +22,8 @@ thresholds crossings, and exact.
 """
 import numpy as np
 
-SLOT_ZA, SLOT_ZB, SLOT_U, SLOT_ZC, SLOT_ZD, SLOT_ZE = range(6)
-NUM_STEP_SLOTS = 6
+SLOT_ZA, SLOT_ZB, SLOT_U, SLOT_ZC, SLOT_ZD, SLOT_ZE, SLOT_ZP = range(7)
+NUM_STEP_SLOTS = 7
 RSLOT_FILL, RSLOT_ZD, RSLOT_ZE = range(3)
 NUM_RESET_SLOTS = 3
 
@@ -61,7 +62,7 @@ def _uniform_from(h):
 
 
 def step_tape(tape_seed, env, step, n):
-    """float32[6, n] tape for (env, step).  `step` counts vector steps since construction
+    """float32[7, n] tape for (env, step).  `step` counts vector steps since construction
     (it is NOT reset by episodes), so auto-resets never replay noise."""
     lane = np.arange(n, dtype=np.uint64)
     out = np.empty((NUM_STEP_SLOTS, n), dtype=np.float32)

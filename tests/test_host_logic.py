@@ -46,11 +46,11 @@ def test_tape_is_bit_stable():
     px, py = T.positions(424242, 3, 50, 500, 500)
     h.update(px.tobytes()); h.update(py.tobytes())
     h.update(T.actions(424242, 3, 100).tobytes())
-    assert h.hexdigest() == "0eb83a6d44671551d0b4d99d7a5b317769f41c398a60b739eacf05ec0e8474c1"
+    assert h.hexdigest() == "45cc9e9990b1b6a06e5d46476d3b27d8eeb44544f33db5ffa4a9a30b25acf2b3"
     st = T.step_tape(1, 0, 0, 4)
-    assert st.dtype == np.float32 and st.shape == (6, 4)
+    assert st.dtype == np.float32 and st.shape == (7, 4)
     assert np.all((st[T.SLOT_U] >= 0) & (st[T.SLOT_U] < 1)) and np.all(np.abs(st[T.SLOT_ZA]) <= 5.0)
-    z = np.concatenate([T.step_tape(5, e, s, 50)[[0, 1, 3, 4, 5]].ravel() for e in range(4) for s in range(20)])
+    z = np.concatenate([T.step_tape(5, e, s, 50)[[0, 1, 3, 4, 5, 6]].ravel() for e in range(4) for s in range(20)])
     assert abs(z.mean()) < 0.05 and abs(z.std() - 1.0206) < 0.03
 
 

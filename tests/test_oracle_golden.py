@@ -90,3 +90,26 @@ def test_invalid_action_raises_after_ageing():
         env.step_tape(7, np.zeros((6, 2), np.float32))
     st = env.state()
     assert st["step"] == 1 and np.all(st["gen"] > gen0)      # uav_env.py:439-468 order
+
+
+@pytest.mark.parametrize("name", G.policy_fixture_names())
+def test_oracle_policies_replay_reference_agents(name):
+    """The oracle's restatement of NearestSensorGreedy / MaxThroughputGreedyV2 picks the action the REAL
+    reference agent picked at every step (fixtures from tests/golden/make_golden_policies.py)."""
+    fx = G.load(name)
+    meta = fx["meta"]
+    n, seed, pid = meta["n"], meta["tape_seed"], meta["policy_id"]
+    cfg = O.default_config(**G.config_overrides(meta))
+    px, py = T.positions(seed, 0, n, meta["grid"][0], meta["grid"][1])
+    env = O.OracleEnv(cfg, 0, px, py)
+    episode = 0
+    assert np.array_equal(env.reset_tape(T.reset_tape(seed, 0, 0, n)), fx["reset_obs"][0])
+    for s in range(meta["steps"]):
+        a, obs, r, tr = env.step_policy_tape(pid, T.step_tape(seed, 0, s, n))
+        assert a == int(fx["actions"][s]), (name, s)
+        assert np.array_equal(obs, fx["obs"][s]) and tr == bool(fx["truncated"][s]), (name, s)
+        assert abs(r - fx["reward"][s]) <= 1e-12 * max(1.0, abs(fx["reward"][s])), (name, s)
+        if tr:
+            episode += 1
+            assert np.array_equal(env.reset_tape(T.reset_tape(seed, 0, episode, n)), fx["reset_obs"][episode])
+    assert len(G.policy_fixture_names()) >= 5
