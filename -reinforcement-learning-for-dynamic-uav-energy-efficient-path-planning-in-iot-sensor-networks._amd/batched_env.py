@@ -140,8 +140,8 @@ class BatchedUAVEnv:
         N.check(self.L.uavenv_set_grid_choices(self._h, len(grids), w, h), self._h)
 
     def set_noise_tape(self, step_tape=None, reset_tape=None):
-        """step_tape: float32 cuda [E, 6, lane_stride]; reset_tape: [E, 3, lane_stride]; None = Philox."""
-        for t, slots in ((step_tape, 6), (reset_tape, 3)):
+        """step_tape: float32 cuda [E, 7, lane_stride]; reset_tape: [E, 3, lane_stride]; None = Philox."""
+        for t, slots in ((step_tape, 7), (reset_tape, 3)):
             if t is not None:
                 assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
                 assert tuple(t.shape) == (self.num_envs, slots, self.lane_stride), tuple(t.shape)
@@ -167,7 +167,7 @@ class BatchedUAVEnv:
 
     def dump_noise(self):
         E, G = self.num_envs, self.lane_stride
-        st = torch.empty(E, 6, G, dtype=torch.float32, device=self.device)
+        st = torch.empty(E, 7, G, dtype=torch.float32, device=self.device)
         rt = torch.empty(E, 3, G, dtype=torch.float32, device=self.device)
         N.check(self.L.uavenv_dump_noise(self._h, self._p(st), self._p(rt), self._stream()), self._h)
         return st, rt
@@ -207,9 +207,18 @@ class BatchedUAVEnv:
                                           self._stream()), self._h)
         return obs, self.reward, self.done
 
-    def rollout(self, num_steps, actions=None, obs_out=None, with_terminal=False):
-        """K steps in ONE launch (uavenv_rollout): `actions` int32 cuda [K, E] or None for the in-kernel random
-        policy.  Returns dict(obs [K,E,D], reward [K,E] f64, reward32, done [K,E] u8, actions [K,E] i32
+    def step_policy(self, policy, obs_out=None):
+        """Step with the action chosen in the kernel: N.POLICY_RANDOM, N.POLICY_NEAREST (NearestSensorGreedy) or
+        N.POLICY_MAX_THROUGHPUT_V2 (greedy_agents.py); the actions land in `self.actions_taken`."""
+        obs = self._obs_target(obs_out)
+        N.check(self.L.uavenv_step_policy(self._h, int(policy), self._p(self.actions_taken), self._p(obs), self._p(self.reward),
+                                          self._p(self.reward32), self._p(self.done), self._p(self.terminal_obs),
+                                          self._stream()), self._h)
+        return obs, self.reward, self.done
+
+    def rollout(self, num_steps, actions=None, obs_out=None, with_terminal=False, policy=None):
+        """K steps in ONE launch (uavenv_rollout): `actions` int32 cuda [K, E], or an in-kernel `policy`
+        (default N.POLICY_RANDOM when no actions are given).  Returns dict(obs [K,E,D], reward [K,E] f64, reward32, done [K,E] u8, actions [K,E] i32
         (+ terminal_obs [K,E,D] when with_terminal)).  Bit-identical to K step() calls."""
         K, E, D, dev = int(num_steps), self.num_envs, self.obs_dim, self.device
         if actions is not None:
@@ -221,7 +230,9 @@ class BatchedUAVEnv:
                    done=torch.empty(K, E, dtype=torch.uint8, device=dev),
                    actions=torch.empty(K, E, dtype=torch.int32, device=dev))
         term = torch.zeros(K, E, D, dtype=torch.float32, device=dev) if with_terminal else None
-        N.check(self.L.uavenv_rollout(self._h, K, self._p(actions), self._p(out["actions"]), self._p(obs),
+        if policy is None:
+            policy = N.POLICY_ACTIONS if actions is not None else N.POLICY_RANDOM
+        N.check(self.L.uavenv_rollout(self._h, K, int(policy), self._p(actions), self._p(out["actions"]), self._p(obs),
                                       self._p(out["reward"]), self._p(out["reward32"]), self._p(out["done"]),
                                       self._p(term), self._stream()), self._h)
         if actions is not None:

@@ -13,7 +13,7 @@ LIB = os.path.join(HERE, "libuavenv_hip.so")
 SOURCES = ["uavenv_kernels.hip", "uavenv_capi.hip"]
 HEADERS = ["uavenv_internal.h", "uavenv_noise.h", os.path.join("..", "..", "include", "uavenv.h")]
 # -ffp-contract=off: the float64 state has to follow the reference's (numpy, unfused) operation order.
-FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall", "-Wno-bitwise-instead-of-logical"]
 
 
 def hipcc():

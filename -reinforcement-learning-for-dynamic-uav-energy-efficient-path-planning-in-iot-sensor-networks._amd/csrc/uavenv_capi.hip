@@ -307,32 +307,41 @@ extern "C" int uavenv_reset(UavEnv* e, const uint8_t* mask_dev, float* obs_out_d
     return UAVENV_OK;
 }
 
-static int step_common(UavEnv* e, const int32_t* actions, int32_t* actions_out, float* obs, double* rew, float* rew32,
-                       uint8_t* done, float* term, void* stream) {
+static int step_common(UavEnv* e, int32_t policy, const int32_t* actions, int32_t* actions_out, float* obs, double* rew,
+                       float* rew32, uint8_t* done, float* term, void* stream) {
     if (!e) return UAVENV_E_INVALID;
+    if (policy < UAVENV_POLICY_ACTIONS || policy > UAVENV_POLICY_MAX_THROUGHPUT_V2) return fail(e, UAVENV_E_INVALID, "unknown policy");
+    if (policy == UAVENV_POLICY_ACTIONS && !actions) return fail(e, UAVENV_E_INVALID, "actions_dev is NULL");
     StepArgs a{actions, actions_out, obs, rew, rew32, done, term, e->num_envs,
-               e->term_pool, e->term_counter, e->term_index, e->term_rows, e->aux_out};
+               e->term_pool, e->term_counter, e->term_index, e->term_rows, policy, e->aux_out};
     HIP_TRY(e, launch_step(e->G, e->padded_envs, e->consts, e->dev_consts, e->ptrs, a, (hipStream_t)stream));
     return UAVENV_OK;
 }
 
 extern "C" int uavenv_step(UavEnv* e, const int32_t* actions_dev, float* obs, double* rew, float* rew32, uint8_t* done,
                            float* term, void* stream) {
-    if (!e || !actions_dev) return e ? fail(e, UAVENV_E_INVALID, "actions_dev is NULL") : UAVENV_E_INVALID;
-    return step_common(e, actions_dev, nullptr, obs, rew, rew32, done, term, stream);
+    return step_common(e, UAVENV_POLICY_ACTIONS, actions_dev, nullptr, obs, rew, rew32, done, term, stream);
 }
 
 extern "C" int uavenv_step_random(UavEnv* e, int32_t* actions_out, float* obs, double* rew, float* rew32, uint8_t* done,
                                   float* term, void* stream) {
-    return step_common(e, nullptr, actions_out, obs, rew, rew32, done, term, stream);
+    return step_common(e, UAVENV_POLICY_RANDOM, nullptr, actions_out, obs, rew, rew32, done, term, stream);
 }
 
-extern "C" int uavenv_rollout(UavEnv* e, int32_t num_steps, const int32_t* actions_dev, int32_t* actions_out, float* obs,
-                              double* rew, float* rew32, uint8_t* done, float* term, void* stream) {
+extern "C" int uavenv_step_policy(UavEnv* e, int32_t policy, int32_t* actions_out, float* obs, double* rew, float* rew32,
+                                  uint8_t* done, float* term, void* stream) {
+    if (policy == UAVENV_POLICY_ACTIONS) return e ? fail(e, UAVENV_E_INVALID, "use uavenv_step for given actions") : UAVENV_E_INVALID;
+    return step_common(e, policy, nullptr, actions_out, obs, rew, rew32, done, term, stream);
+}
+
+extern "C" int uavenv_rollout(UavEnv* e, int32_t num_steps, int32_t policy, const int32_t* actions_dev, int32_t* actions_out,
+                              float* obs, double* rew, float* rew32, uint8_t* done, float* term, void* stream) {
     if (!e) return UAVENV_E_INVALID;
     if (num_steps <= 0) return fail(e, UAVENV_E_INVALID, "num_steps must be positive");
+    if (policy < UAVENV_POLICY_ACTIONS || policy > UAVENV_POLICY_MAX_THROUGHPUT_V2) return fail(e, UAVENV_E_INVALID, "unknown policy");
+    if (policy == UAVENV_POLICY_ACTIONS && !actions_dev) return fail(e, UAVENV_E_INVALID, "actions_dev is NULL");
     StepArgs a{actions_dev, actions_out, obs, rew, rew32, done, term, e->num_envs,
-               e->term_pool, e->term_counter, nullptr, e->term_rows, e->aux_out};   // aux [K][E][4] carries the pool rows
+               e->term_pool, e->term_counter, nullptr, e->term_rows, policy, e->aux_out};   // aux [K][E][4] carries the pool rows
     HIP_TRY(e, launch_rollout(e->G, e->padded_envs, e->consts, e->dev_consts, e->ptrs, a, num_steps, (hipStream_t)stream));
     return UAVENV_OK;
 }
@@ -439,7 +448,7 @@ extern "C" int uavenv_time_steps(UavEnv* e, int32_t steps, float* obs, double* r
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(e, hipEventRecord(e->ev0, s));
     for (int i = 0; i < steps; i++) {
-        int rc = step_common(e, nullptr, nullptr, obs, rew, nullptr, done, nullptr, stream);
+        int rc = step_common(e, UAVENV_POLICY_RANDOM, nullptr, nullptr, obs, rew, nullptr, done, nullptr, stream);
         if (rc) return rc;
     }
     HIP_TRY(e, hipEventRecord(e->ev1, s));

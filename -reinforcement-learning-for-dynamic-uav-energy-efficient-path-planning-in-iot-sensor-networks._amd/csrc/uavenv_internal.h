@@ -79,6 +79,7 @@ struct StepArgs {
     uint32_t* term_counter;
     int32_t* term_index;
     int32_t term_rows;
+    int32_t policy;             // UAVENV_POLICY_*
     float* aux;                 // optional float [E][4] = (action, reward, done, terminal-pool row or -1): the packed
                                 // remainder of a transition block, so that replay insertion needs no pack kernel
 };

@@ -388,6 +388,77 @@ __device__ __forceinline__ void observe(CRef c, Sensor& s, int n, int gw, int gh
 // words are kept and converted on demand (finish_zc).
 struct StepNoise { float zA, zB, u, zC, zD, zE; uint32_t c2, c3; bool zc_ready; };
 
+// zP: the shadowing sample of the is_in_range() call a heuristic policy makes before the step (Philox call 5)
+template <int G>
+__device__ __forceinline__ float draw_policy_noise(CRef c, const Ptrs& p, uint32_t env_index, uint32_t episode, size_t env,
+                                                   bool in_batch, uint32_t step) {
+    const int gl = group_lane<G>();
+    if (p.step_tape != nullptr)
+        return in_batch ? p.step_tape[env * (size_t)(UAVENV_TAPE_STEP_SLOTS * G) + UAVENV_TAPE_ZP * G + gl] : 0.0f;
+    Words4 w = noise_words(c.seed, env_index, episode, step, (uint32_t)gl, 5);
+    float zP, spare;
+    normal_pair(w.w0, w.w1, zP, spare);
+    return zP;
+}
+
+// greedy_agents.py:42-67 GreedyAgent._move_toward (float32 position arithmetic; group-uniform inputs)
+__device__ __forceinline__ int policy_move_toward(float ux, float uy, int gw, int gh, float tx, float ty) {
+    const float dx = tx - ux, dy = ty - uy;
+    const bool here = (fabsf(dx) <= 0.5f) & (fabsf(dy) <= 0.5f);
+    const bool horiz = fabsf(dx) > fabsf(dy);
+    const float nx = horiz ? ux + (dx > 0 ? 1.0f : -1.0f) : ux;
+    const float ny = horiz ? uy : uy + (dy > 0 ? 1.0f : -1.0f);
+    const bool out = (nx < 0) | (nx >= (float)gw) | (ny < 0) | (ny >= (float)gh);
+    const float mdx = nx - ux, mdy = ny - uy;
+    const int mv = mdx > 0 ? 3 : (mdx < 0 ? 2 : (mdy > 0 ? 0 : (mdy < 0 ? 1 : 4)));
+    return (here | out) ? 4 : mv;
+}
+
+// Heuristic policies evaluated on device for the CURRENT state of one environment group:
+//   UAVENV_POLICY_NEAREST            greedy_agents.py:73-100   collect if any sensor with data is in range, else
+//                                                             step toward the nearest sensor with data
+//   UAVENV_POLICY_MAX_THROUGHPUT_V2  greedy_agents.py:105-216  collect if an in-range sensor with data has an
+//                                                             acceptable SF, else step toward the best-scored one
+// Python's min()/`score > best` keep the FIRST extremum: the lowest lane among equal keys.
+template <int G>
+__device__ __forceinline__ int policy_action(CRef c, const Sensor& s, const Env& e, bool act, int policy, float zP) {
+    const int gl = group_lane<G>();
+    const double det = rssi_deterministic(c, e.ux, e.uy, s.sx, s.sy);
+    const bool has = act & (s.b > 0);
+    const bool in_range = has & ((det + c.sigma * (double)zP) >= c.thr);          // iot_sensors.py:214-219
+    const float dx = s.sx - e.ux, dy = s.sy - e.uy;
+    const float dist = sqrt_rn(dx * dx + dy * dy);                                // np.linalg.norm, float32
+    bool collect;
+    uint64_t pick;
+    if (policy == UAVENV_POLICY_NEAREST) {
+        collect = gany<G>(in_range);
+        const float dm = gmin_f32<G>(has ? dist : __builtin_inff());
+        pick = gballot<G>(has & (dist == dm));
+    } else {
+        const double battery_pct = e.battery / 274.0;                              // greedy_agents.py:133 (hard-coded)
+        const int steps_left = c.max_steps - e.step;
+        const double r = (double)steps_left / (double)c.max_steps;
+        const double steps_ratio = r < 1.0 ? r : 1.0;
+        const int sf_thr = ((battery_pct > 0.5) & (steps_ratio > 0.5)) ? 9 : (((battery_pct > 0.2) & (steps_ratio > 0.2)) ? 10 : 12);
+        const int sf = (int)(s.flags & kSfMask);
+        collect = gany<G>(in_range & (sf <= sf_thr));
+        const double sf_w = ((battery_pct < 0.1) | (steps_left < 50)) ? 1.0 : (((battery_pct < 0.3) | (steps_left < 150)) ? 2.0 : 5.0);
+        const int pr = 13 - sf > 0 ? 13 - sf : 0;
+        const double sf_score = pr * 5.0 * sf_w;
+        const double buffer_score = (s.b / c.bmax) * 10.0;
+        const double duty_score = c.p_cycle * 2.0;                                // (duty_cycle / 100) * 2
+        const float distance_penalty = ((dist / (float)e.gw) * 5.0f) * 1.0f;
+        const double score = ((sf_score + buffer_score) + duty_score) - (double)distance_penalty;
+        const double sm = gmax<G>(has ? score : -__builtin_inf());
+        pick = gballot<G>(has & (score == sm));
+    }
+    const int target = pick ? (__ffsll((long long)pick) - 1) : 0;
+    const float tx = gshfl<G>(s.sx, target), ty = gshfl<G>(s.sy, target);
+    const int mv = policy_move_toward(e.ux, e.uy, e.gw, e.gh, tx, ty);
+    (void)gl;
+    return (collect | (pick == 0ull)) ? 4 : mv;
+}
+
 template <int G>
 __device__ __forceinline__ void draw_step_noise(CRef c, const Ptrs& p, uint32_t env_index, uint32_t episode,
                                                 size_t env, bool in_batch, uint32_t step, bool need_collect, StepNoise& z) {
@@ -397,7 +468,8 @@ __device__ __forceinline__ void draw_step_noise(CRef c, const Ptrs& p, uint32_t 
         z.zA = z.zB = z.zC = z.zD = z.zE = 0.f; z.u = 1.f;
         if (in_batch) {                                // the tape has no rows for the padding environments
             const float* t = p.step_tape + env * (size_t)(UAVENV_TAPE_STEP_SLOTS * G) + gl;
-            z.zA = t[0 * G]; z.zB = t[1 * G]; z.u = t[2 * G]; z.zC = t[3 * G]; z.zD = t[4 * G]; z.zE = t[5 * G];
+            z.zA = t[UAVENV_TAPE_ZA * G]; z.zB = t[UAVENV_TAPE_ZB * G]; z.u = t[UAVENV_TAPE_U * G];
+            z.zC = t[UAVENV_TAPE_ZC * G]; z.zD = t[UAVENV_TAPE_ZD * G]; z.zE = t[UAVENV_TAPE_ZE * G];
         }
         return;
     }
@@ -577,7 +649,11 @@ __device__ __forceinline__ void step_once(CRef c, const Ptrs& p, const StepArgs&
     // ---- action -----------------------------------------------------------------------------
     const uint32_t step = (uint32_t)(e.step + 1);
     int action;
-    if (a.actions != nullptr) action = uni<G>(in_batch ? a.actions[env] : 0);
+    if (a.policy >= UAVENV_POLICY_NEAREST) {                    // heuristic baseline evaluated on device
+        const float zP = draw_policy_noise<G>(c, p, e.env_index, e.episode, env, in_batch, step);
+        action = uni<G>(policy_action<G>(c, s, e, act, a.policy, zP));
+        if (a.actions_out != nullptr && in_batch && gl == 0) a.actions_out[env] = action;
+    } else if (a.policy == UAVENV_POLICY_ACTIONS) action = uni<G>(in_batch ? a.actions[env] : 0);
     else {                                                       // uniform-random policy (Philox call 3)
         Words4 w = noise_words(c.seed, e.env_index, e.episode, step, 0u, 3);
         action = (int)(((uint64_t)w.w0 * 5u) >> 32);
@@ -995,6 +1071,7 @@ __global__ __launch_bounds__(kBlockThreads) void uav_dump_noise_kernel(const Con
         finish_zc(z);
         float* t = step_tape + env * (size_t)(UAVENV_TAPE_STEP_SLOTS * G) + gl;
         t[0 * G] = z.zA; t[1 * G] = z.zB; t[2 * G] = z.u; t[3 * G] = z.zC; t[4 * G] = z.zD; t[5 * G] = z.zE;
+        t[UAVENV_TAPE_ZP * G] = draw_policy_noise<G>(c, q, r.env_index, r.episode, env, true, (uint32_t)(r.current_step + 1));
     }
     if (reset_tape) {
         uint32_t ep = r.episode + 1u;

@@ -128,7 +128,14 @@ enum {
 
 /* noise-tape slots (float [E][slots][stride]); NULL tape = in-kernel Philox4x32-10 */
 enum { UAVENV_TAPE_ZA = 0, UAVENV_TAPE_ZB, UAVENV_TAPE_U, UAVENV_TAPE_ZC, UAVENV_TAPE_ZD, UAVENV_TAPE_ZE,
+       UAVENV_TAPE_ZP,          /* in-range sample drawn by a heuristic policy before the step */
        UAVENV_TAPE_STEP_SLOTS };
+
+/* action sources for uavenv_step_policy / uavenv_rollout */
+#define UAVENV_POLICY_ACTIONS            0   /* actions_dev                                                   */
+#define UAVENV_POLICY_RANDOM             1   /* uniform random (Philox call 3), BASELINE.md section 4         */
+#define UAVENV_POLICY_NEAREST            2   /* greedy_agents.py:73-100  NearestSensorGreedy, on device       */
+#define UAVENV_POLICY_MAX_THROUGHPUT_V2  3   /* greedy_agents.py:105-216 MaxThroughputGreedyV2, on device     */
 enum { UAVENV_RTAPE_FILL = 0, UAVENV_RTAPE_ZD, UAVENV_RTAPE_ZE, UAVENV_RTAPE_SLOTS };
 
 typedef struct UavEnv UavEnv;
@@ -164,7 +171,7 @@ int uavenv_set_seed(UavEnv* env, uint64_t seed);
 int uavenv_set_grid_choices(UavEnv* env, int32_t count, const int32_t* w, const int32_t* h);
 
 /* ---- noise tape (parity testing) ------------------------------------------------------------ */
-/* step_tape_dev: float [E][6][stride] consumed by the next uavenv_step; reset_tape_dev:
+/* step_tape_dev: float [E][7][stride] consumed by the next uavenv_step; reset_tape_dev:
  * float [E][3][stride] consumed by uavenv_reset and by auto-resets.  NULL restores Philox. */
 int uavenv_set_noise_tape(UavEnv* env, const float* step_tape_dev, const float* reset_tape_dev);
 /* writes the tapes the NEXT step (and a reset opening the next episode) would draw from Philox */
@@ -192,14 +199,20 @@ int uavenv_step(UavEnv* env, const int32_t* actions_dev, float* obs_out_dev, dou
 int uavenv_step_random(UavEnv* env, int32_t* actions_out_dev, float* obs_out_dev, double* reward_out_dev,
                        float* reward32_out_dev, uint8_t* done_out_dev, float* terminal_obs_dev, void* stream);
 
-/* K consecutive steps in ONE launch (SURVEY 8b "uavenv_step_k"): open-loop actions (actions_dev int32
- * [K][E]) or, with actions_dev == NULL, the in-kernel uniform-random policy.  Sensor state stays in
+/* same, with the action chosen IN the kernel by `policy` (UAVENV_POLICY_RANDOM / _NEAREST / _MAX_THROUGHPUT_V2):
+ * replaces agent.select_action(obs) + env.step(action) of the heuristic baselines (greedy_agents.py; used by the
+ * curriculum gate dqn.py:456-543), whose is_in_range() samples come from Philox call 5 / tape slot zP. */
+int uavenv_step_policy(UavEnv* env, int32_t policy, int32_t* actions_out_dev, float* obs_out_dev, double* reward_out_dev,
+                       float* reward32_out_dev, uint8_t* done_out_dev, float* terminal_obs_dev, void* stream);
+
+/* K consecutive steps in ONE launch (SURVEY 8b "uavenv_step_k"): policy UAVENV_POLICY_ACTIONS = open-loop
+ * actions (actions_dev int32 [K][E]), otherwise an in-kernel policy (random or heuristic).  Sensor state stays in
  * registers and the record in LDS for the whole launch, but EVERY step still writes its block:
  * obs_out_dev [K][E][obs_dim], reward [K][E], done [K][E], actions_out [K][E] (each nullable), e.g. K
  * consecutive slots of a replay ring.  Bit-identical to K uavenv_step / uavenv_step_random launches.
  * replaces: the `for _ in range(K): env.step(policy(obs))` loop of uav_env.py:935-960 / SB3
  * collect_rollouts for policies that do not read the observation (random warm-up, action replay). */
-int uavenv_rollout(UavEnv* env, int32_t num_steps, const int32_t* actions_dev, int32_t* actions_out_dev,
+int uavenv_rollout(UavEnv* env, int32_t num_steps, int32_t policy, const int32_t* actions_dev, int32_t* actions_out_dev,
                    float* obs_out_dev, double* reward_out_dev, float* reward32_out_dev, uint8_t* done_out_dev,
                    float* terminal_obs_dev, void* stream);
 

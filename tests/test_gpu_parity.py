@@ -35,7 +35,7 @@ def _rel(a, b):
 
 
 def _tape_tensors(torch, seed, envs, step, n, stride, device):
-    st = np.zeros((len(envs), 6, stride), np.float32)
+    st = np.zeros((len(envs), T.NUM_STEP_SLOTS, stride), np.float32)
     for k, e in enumerate(envs):
         st[k, :, :n] = T.step_tape(seed, e, step, n)
     return torch.from_numpy(st).to(device)
@@ -122,7 +122,7 @@ def test_noise_matches_oracle_bit_for_bit():
         rec = env.records()
         L = O.lib()
         for k in range(7):
-            want = np.zeros((6, n), np.float32)
+            want = np.zeros((7, n), np.float32)
             L.orc_noise_step_tape(0x1234ABCD9876, 1000 + k, int(rec["episode"][k]), int(rec["current_step"][k]) + 1, n,
                                   O._fp(want))
             assert np.array_equal(st[k, :, :n], want), (n, k)
@@ -365,4 +365,60 @@ def test_fused_rollout_is_bit_identical_to_single_steps(n, flags):
     sa, sb = a.state_dict(), b.state_dict()
     for key in sa:
         assert torch.equal(sa[key], sb[key]), key
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("name", G.policy_fixture_names())
+def test_hip_policies_replay_reference_agents(name):
+    """On-device NearestSensorGreedy / MaxThroughputGreedyV2 (uavenv_step_policy) choose the action the REAL
+    reference agent chose at every step, and the resulting trajectory matches (tape incl. slot zP)."""
+    torch, U, O = _mods()
+    fx = G.load(name)
+    meta = fx["meta"]
+    n, seed, pid = meta["n"], meta["tape_seed"], meta["policy_id"]
+    E = 2
+    px, py = T.positions(seed, 0, n, meta["grid"][0], meta["grid"][1])
+    env = U.BatchedUAVEnv(E, auto_reset=True, sensor_positions=np.stack([px, py], -1), **G.config_overrides(meta))
+    S, dev = env.lane_stride, env.device
+    env.set_noise_tape(None, _reset_tape_tensor(torch, seed, [0] * E, [0] * E, n, S, dev))
+    assert np.array_equal(env.reset().cpu().numpy()[1], fx["reset_obs"][0])
+    episode = 0
+    for s in range(meta["steps"]):
+        env.set_noise_tape(_tape_tensors(torch, seed, [0] * E, s, n, S, dev),
+                           _reset_tape_tensor(torch, seed, [0] * E, [episode + 1] * E, n, S, dev))
+        o, r, d = env.step_policy(pid)
+        a = env.actions_taken.cpu().numpy()
+        assert a[0] == a[1] == int(fx["actions"][s]), (name, s, a, int(fx["actions"][s]))
+        tr = bool(fx["truncated"][s])
+        step_obs = (env.terminal_obs if tr else o).cpu().numpy()
+        assert np.max(np.abs(step_obs[1] - fx["obs"][s])) <= OBS_ATOL, (name, s)
+        assert _rel(r.cpu().numpy()[1], fx["reward"][s]) <= REW_RTOL and bool(d[1]) == tr, (name, s)
+        if tr:
+            episode += 1
+            assert np.array_equal(o.cpu().numpy()[1], fx["reset_obs"][episode])
+    env.close()
+
+
+@pytest.mark.parametrize("policy,n", [(2, 50), (3, 50), (3, 20), (2, 10)])
+def test_policy_rollouts_match_oracle_and_fuse(policy, n):
+    """Keyed (Philox) policy rollouts: per-step kernel == oracle, and the fused K-step kernel == per-step."""
+    torch, U, O = _mods()
+    E, steps, seed = 40, 120, 77
+    over = dict(num_sensors=n, grid_size=(1500, 1500), max_steps=70, duty_cycle=40.0)      # large grid: the policies must navigate
+    want = O.trace_keyed(O.default_config(seed=seed, **over), E, steps, policy=policy)
+    a = U.BatchedUAVEnv(E, seed=seed, **over)
+    b = U.BatchedUAVEnv(E, seed=seed, **over)
+    assert np.array_equal(a.reset().cpu().numpy(), want["reset_obs"]); b.reset()
+    ro = b.rollout(steps, policy=policy)
+    moves = 0
+    for s in range(steps):
+        o, r, d = a.step_policy(policy)
+        act = a.actions_taken.cpu().numpy()
+        assert np.array_equal(act, want["actions"][s]), s
+        assert np.array_equal(d.cpu().numpy(), want["done"][s])
+        assert np.max(np.abs(o.cpu().numpy() - want["obs"][s])) <= OBS_ATOL
+        assert np.max(_rel(r.cpu().numpy(), want["reward"][s])) <= REW_RTOL
+        assert torch.equal(ro["obs"][s], o) and torch.equal(ro["reward"][s], r) and torch.equal(ro["actions"][s], a.actions_taken)
+        moves += int((act != 4).sum())
+    assert moves > 0 and want["done"].any()
     a.close(); b.close()
