@@ -182,16 +182,17 @@ def main():
     workload_key = f"{E}x{n}@{args.grid}"
     tr = latest_traffic(workload_key)
     out = {
-        "metric": "env-steps/sec at 4096 envs x 50 sensors (HBM GB/s vs peak in roofline)",
+        "metric": "env-steps/sec at 4096 envs\u00d750 sensors, 1/2/4/8 MI355X; HBM GB/s vs peak",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64 state / f32 distances+observations", "data": "synthetic",
+        "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{E} envs/GPU x {n} sensors, {args.grid}x{args.grid} grid, BASE_ENV_CONFIG, "
                                f"uniform-random policy (in-kernel Philox), auto-reset, obs+reward+done written every step",
                    "envs_per_gpu": E, "sensors": n, "grid": args.grid, "obs_dim": env.obs_dim,
                    "exchange": ("rccl all_gather of the transition block per step into a shared replay ring"
                                 if exchange == "allgather" else "none (observations written in place into the replay ring)"),
-                   "parallelism": f"env-shard x{world}"},
+                   "parallelism": f"env-shard x{world}",
+                   "arithmetic": "float64 state and rewards, float32 distance chain and observations (the reference's own mix)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": (tr or {}).get("hbm_bytes_per_launch"),
