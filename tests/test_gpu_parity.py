@@ -422,3 +422,30 @@ def test_policy_rollouts_match_oracle_and_fuse(policy, n):
         moves += int((act != 4).sum())
     assert moves > 0 and want["done"].any()
     a.close(); b.close()
+
+
+def test_full_episode_parity_including_natural_truncation():
+    """A whole reference-length episode and beyond (2300 steps > max_steps 2100; battery death at 1381-1933 steps)
+    for 64 envs x 50 sensors under the random policy: the float64 state must not drift (observations stay within
+    1e-6, rewards within 1e-9 relative, every truncation and auto-reset on the same step as the oracle)."""
+    torch, U, O = _mods()
+    E, steps, seed = 64, 2300, 4242
+    want = O.trace_keyed(O.default_config(num_sensors=50, seed=seed), E, steps, base=123)
+    env = U.BatchedUAVEnv(E, num_sensors=50, seed=seed, env_index_base=123)
+    assert np.array_equal(env.reset().cpu().numpy(), want["reset_obs"])
+    K = 100
+    for s0 in range(0, steps, K):
+        ro = env.rollout(K, with_terminal=True)
+        o, r, d = ro["obs"].cpu().numpy(), ro["reward"].cpu().numpy(), ro["done"].cpu().numpy()
+        sl = slice(s0, s0 + K)
+        assert np.array_equal(d, want["done"][sl]), s0
+        assert np.array_equal(ro["actions"].cpu().numpy(), want["actions"][sl]), s0
+        assert np.max(np.abs(o - want["obs"][sl])) <= OBS_ATOL, (s0, np.max(np.abs(o - want["obs"][sl])))
+        assert np.max(_rel(r, want["reward"][sl])) <= REW_RTOL, s0
+        m = d.astype(bool)
+        if m.any():
+            assert np.max(np.abs(ro["terminal_obs"].cpu().numpy()[m] - want["term_obs"][sl][m])) <= OBS_ATOL
+    assert want["done"].sum() >= E                      # every environment finished at least one episode
+    lens = env.episode_stats()["length"]
+    assert lens.min() >= 1381 and lens.max() <= 2100    # SURVEY 8a a13: all-hover 1381 ... max_steps 2100
+    env.close()
