@@ -155,22 +155,32 @@ template <int G> __device__ __forceinline__ float np_sum_f32(float a, int n) {
 // ---------------------------------------------------------------------------------------------
 // LoRa tables: iot_sensors.py:13-20 (bytes/s), :22-29 (required SNR dB); uav_env.py:647 (link quality)
 // ---------------------------------------------------------------------------------------------
+// All three tables are written as flat select sequences (v_cndmask), not nested ternaries: the nested form
+// compiles to a tree of exec-mask branches.
 __device__ __forceinline__ double sf_data_rate(uint32_t sf) {
-    return sf == 7 ? 5470 / 8.0 : sf == 8 ? 3125 / 8.0 : sf == 9 ? 1760 / 8.0 : sf == 10 ? 980 / 8.0
-         : sf == 11 ? 440 / 8.0 : 250 / 8.0;
+    double r = 250 / 8.0;                       // SF12 (and anything unknown, like the reference's table lookup of 12)
+    r = sf == 11 ? 440 / 8.0 : r;
+    r = sf == 10 ? 980 / 8.0 : r;
+    r = sf == 9 ? 1760 / 8.0 : r;
+    r = sf == 8 ? 3125 / 8.0 : r;
+    r = sf == 7 ? 5470 / 8.0 : r;
+    return r;
 }
 __device__ __forceinline__ double sf_required_snr(uint32_t sf) {
-    return sf == 7 ? -6.0 : sf == 8 ? -9.0 : sf == 9 ? -12.0 : sf == 10 ? -15.0 : sf == 11 ? -17.5
-         : sf == 12 ? -20.0 : 7.5;
+    // -6, -9, -12, -15, -17.5, -20 for SF 7..12 (7.5 otherwise, iot_sensors.py:200)
+    double r = 7.5;
+    r = ((sf >= 7u) & (sf <= 10u)) ? -6.0 - 3.0 * (double)(int)(sf - 7u) : r;   // exact small integers
+    r = sf == 11u ? -17.5 : r;
+    r = sf == 12u ? -20.0 : r;
+    return r;
 }
-__device__ __forceinline__ double sf_link_quality(uint32_t sf) {
-    return sf == 7 ? 1.0 : sf == 8 ? 0.8 : sf == 9 ? 0.6 : sf == 10 ? 0.4 : sf == 11 ? 0.2 : 0.1;
+// uav_env.py:647 sf_quality {7: 1.0, 8: .8, 9: .6, 10: .4, 11: .2, 12: .1} as the float32 the observation stores:
+// 0.2f * k reproduces float32(1.0, 0.8, 0.6, 0.4, 0.2) bit for bit for k = 5..1 (checked), 0.1f otherwise.
+__device__ __forceinline__ float sf_link_quality_f32(uint32_t sf) {
+    const float k = (float)(int)(12u - sf);
+    return ((sf >= 7u) & (sf <= 11u)) ? 0.2f * k : 0.1f;
 }
 
-// iot_sensors.py:147-189: deterministic RSSI.  Distances and 20*log10f(d) in float32, sums in
-// float64, exactly the reference's mix.  log10 of the float32 distance is evaluated in float64 and
-// rounded once, i.e. the correctly rounded float32 log10 (the reference's own np.log10(float32) is
-// platform dependent at the 1-ulp level; see oracle/uavenv_oracle.h).
 // log10 of a positive normal float32, evaluated in float64 and rounded once to float32.
 // Specification shared with the oracle (oracle/uavenv_oracle.c:orc_log10_f32), IEEE + - * / only:
 // x = m * 2^e with m folded into [sqrt(1/2), sqrt(2)); ln m = 2 atanh(s), s = (m-1)/(m+1), by the odd
@@ -219,14 +229,15 @@ __device__ __forceinline__ double rssi_deterministic(CRef c, float ux, float uy,
 
 // iot_sensors.py:223-259 update_spreading_factor (EMA-ADR), state in (avg, flags)
 __device__ __forceinline__ void adr_update(CRef c, double cur, double& avg, uint32_t& flags) {
-    double nv = cur;
-    if ((flags & kAvgValid) && c.use_ema) nv = (c.lambda * cur) + (c.one_minus_lambda * avg);
+    const bool ema = ((flags & kAvgValid) != 0u) & (c.use_ema != 0);
+    const double blended = (c.lambda * cur) + (c.one_minus_lambda * avg);
+    const double nv = ema ? blended : cur;
     avg = nv;
-    uint32_t sf = flags & kSfMask;
-    if (nv > c.sf_thr[0]) sf = 7;
-    else if (nv > c.sf_thr[1]) sf = 9;
-    else if (nv > c.sf_thr[2]) sf = 11;
-    else if (nv > c.sf_thr[3]) sf = 12;          // else: sticky (iot_sensors.py:251-255)
+    uint32_t sf = flags & kSfMask;                     // sticky when no threshold fires (iot_sensors.py:251-255)
+    sf = nv > c.sf_thr[3] ? 12u : sf;                  // later assignments win = the FIRST matching threshold of the
+    sf = nv > c.sf_thr[2] ? 11u : sf;                  // reference's descending list (-60, -70, -78, -85)
+    sf = nv > c.sf_thr[1] ? 9u : sf;
+    sf = nv > c.sf_thr[0] ? 7u : sf;
     flags = (flags & ~kSfMask) | sf | kAvgValid;
 }
 
@@ -350,7 +361,7 @@ __device__ __forceinline__ void observe(CRef c, Sensor& s, int n, int gw, int gh
         bool in_range = (det + c.sigma * (double)zE) >= c.thr;               // :658, iot_sensors.py:214-219
         f0 = (float)div_const(s.b, c.bmax, c.inv_bmax);
         f1 = (float)urgency;
-        f2 = (float)(in_range ? sf_link_quality(s.flags & kSfMask) : 0.0);
+        f2 = in_range ? sf_link_quality_f32(s.flags & kSfMask) : 0.0f;
         if (c.fps == 5) {                                                     // :668-672
             f3 = (float)div_const((double)s.sx - ux, W, inv_w);
             f4 = (float)div_const((double)s.sy - uy, H, inv_h);
