@@ -449,3 +449,36 @@ def test_full_episode_parity_including_natural_truncation():
     lens = env.episode_stats()["length"]
     assert lens.min() >= 1381 and lens.max() <= 2100    # all-hover 1381 ... max_steps 2100
     env.close()
+
+
+def test_mixed_grid_and_sensor_count_in_one_handle():
+    """BASELINE config 5 interleaves (grid, N) combinations: per-environment grid and sensor count inside ONE
+    handle (uavenv_set_env_params), every environment checked against its own oracle instance."""
+    torch, U, O = _mods()
+    E, steps, seed = 48, 150, 31
+    ns = np.array([10, 20, 33, 50])[np.arange(E) % 4].astype(np.int32)
+    grids = np.array([250, 500, 1000])[np.arange(E) % 3].astype(np.int32)
+    rng = np.random.default_rng(0)
+    pos = np.zeros((E, 50, 2), np.float32)
+    for k in range(E):
+        pos[k, :ns[k]] = (rng.random((ns[k], 2)) * grids[k]).astype(np.float32)
+    env = U.BatchedUAVEnv(E, num_sensors=50, seed=seed, max_steps=60, duty_cycle=50.0, sensor_positions=pos)
+    env.set_env_params(grid_w=grids, grid_h=grids, num_sensors=ns)
+    orcs = []
+    for k in range(E):
+        cfg = O.default_config(num_sensors=int(ns[k]), pad_sensors=50, grid_size=(int(grids[k]), int(grids[k])), seed=seed,
+                               max_steps=60, duty_cycle=50.0)
+        orcs.append(O.OracleEnv(cfg, k, pos[k, :ns[k], 0], pos[k, :ns[k], 1]))
+    o = env.reset().cpu().numpy()
+    for k in range(E):
+        assert np.array_equal(o[k], orcs[k].reset_keyed()), k
+    for s in range(steps):
+        o, r, d = env.step_random()
+        o, r, d, a = o.cpu().numpy(), r.cpu().numpy(), d.cpu().numpy(), env.actions_taken.cpu().numpy()
+        for k in range(E):
+            assert a[k] == orcs[k].next_random_action(), (s, k)
+            oo, rr, tr = orcs[k].step_keyed(int(a[k]))
+            if tr:
+                oo = orcs[k].reset_keyed()
+            assert np.max(np.abs(o[k] - oo)) <= OBS_ATOL and _rel(r[k], rr) <= REW_RTOL and bool(d[k]) == tr, (s, k)
+    env.close()
