@@ -10,8 +10,7 @@ sys.path.insert(0, ROOT)
 PKG = os.path.join(ROOT, "-reinforcement-learning-for-dynamic-uav-energy-efficient-path-planning-in-iot-sensor-networks._amd")
 OUT = os.path.join(ROOT, "gpurun_out", "ablate")
 os.makedirs(OUT, exist_ok=True)
-VARIANTS = [("base", []), ("no_log10", ["-DUAV_ABL_LOG10"]), ("philox6", ["-DUAV_ABL_PHILOX=6"]),
-            ("philox8", ["-DUAV_ABL_PHILOX=8"])]
+VARIANTS = [("base", []), ("no_log10", ["-DUAV_ABL_LOG10"]), ("philox6", ["-DUAV_ABL_PHILOX=6"]), ("no_normal", ["-DUAV_ABL_NORMAL"])]
 VARIANTS += [(n, f.split()) for n, f in (x.split("=", 1) for x in sys.argv[1:])]
 procs = []
 for name, flags in VARIANTS:
