@@ -50,7 +50,7 @@ class UAVVecEnv(_Base):
     """
 
     def __init__(self, num_envs, domain_rand=False, curriculum_stage=0, max_sensors_limit=MAX_SENSORS_LIMIT,
-                 device=None, env_index_base=0, **config):
+                 device=None, env_index_base=0, n_stack=1, **config):
         flags = 0
         if domain_rand:
             flags = N.FLAG_RANDOM_LAYOUT | N.FLAG_FAR_START | N.FLAG_PROX_SHAPING | N.FLAG_JAIN_BONUS
@@ -61,7 +61,14 @@ class UAVVecEnv(_Base):
                                  flags=flags, **config)
         self._domain_rand = domain_rand
         self._curriculum_stage = curriculum_stage
-        D = self.env.obs_dim
+        # n_stack > 1 folds SB3's VecFrameStack(n_stack) (dqn.py:1278) into this env: the stack is kept on the GPU
+        # by uavenv_frame_stack and only the stacked observation is copied to the host.
+        self.n_stack = int(n_stack)
+        self._fs = None
+        if self.n_stack > 1:
+            from .frame_stack import FrameStack
+            self._fs = FrameStack(num_envs, self.env.obs_dim, self.n_stack, self.env.device)
+        D = self.env.obs_dim * self.n_stack
         if domain_rand:
             obs_space = spaces.Box(low=-np.inf, high=np.inf, shape=(D,), dtype=np.float32)      # dqn.py:252-254
         else:
@@ -74,7 +81,10 @@ class UAVVecEnv(_Base):
 
     # ---- SB3 VecEnv contract --------------------------------------------------------------------
     def reset(self):
-        return self.env.reset().cpu().numpy()
+        obs = self.env.reset()
+        if self._fs is not None:
+            obs = self._fs.reset(obs)
+        return obs.cpu().numpy()
 
     def step_async(self, actions):
         a = np.asarray(actions)
@@ -90,13 +100,17 @@ class UAVVecEnv(_Base):
         assert self._pending
         self._pending = False
         env = self.env
-        obs = env.obs.cpu().numpy()
+        if self._fs is not None:
+            obs = self._fs.step(env.obs, env.done, env.terminal_obs).cpu().numpy()
+        else:
+            obs = env.obs.cpu().numpy()
         rews = env.reward32.cpu().numpy()
         dones = env.done.cpu().numpy().astype(bool)
         infos = [{} for _ in range(self.num_envs)]
         if dones.any():
             idx = np.nonzero(dones)[0]
-            term = env.terminal_obs[torch.from_numpy(idx).to(env.device)].cpu().numpy()
+            src = self._fs.terminal_stacked if self._fs is not None else env.terminal_obs
+            term = src[torch.from_numpy(idx).to(env.device)].cpu().numpy()
             stats = env.episode_stats()
             now = round(time.time() - self._t0, 6)
             for j, i in enumerate(idx):

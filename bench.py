@@ -172,7 +172,7 @@ def main():
         fused = {"steps_per_launch": F, "launches": launches, "ms_per_launch": fms,
                  "env_steps_per_s": E * F / (fms * 1e-3),
                  "achieved_GBps": algorithmic_bytes_per_env_step(n) * E * F / (fms * 1e-3) / 1e9,
-                 "kernel": "uav_rollout_kernel<64>"}
+                 "kernel": "uav_rollout_kernel<64, true>"}
 
     total_env_steps = E * K * world
     value = total_env_steps / dt
@@ -196,7 +196,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": (tr or {}).get("hbm_bytes_per_launch"),
-                     "kernel": "uav_step_kernel<64>", "algorithmic_bytes_per_launch": per_launch_bytes,
+                     "kernel": "uav_step_kernel<64, true>", "algorithmic_bytes_per_launch": per_launch_bytes,
                      "algorithmic_bytes_per_env_step": B, "avg_launch_ms": kern_ms,
                      "timed_region_event_ms_per_step": ev_ms / K,
                      "note": "path is VALU/latency bound (Philox + float64 physics per sensor), not HBM bound: "

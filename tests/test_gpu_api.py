@@ -276,3 +276,30 @@ def test_stacked_sampling_equals_frame_stack():
             assert torch.equal(b["next_obs"][i], stacks[s + 1][ei])
     assert checked_term > 5 and b["valid"].all()
     env.close()
+
+
+def test_vec_env_with_builtin_frame_stack():
+    """UAVVecEnv(n_stack=k) == VecFrameStack(k) over UAVVecEnv (SB3 semantics restated in numpy above)."""
+    torch, U, O = _mods()
+    E, k = 5, 4
+    kw = dict(num_sensors=10, grid_size=(80, 80), max_steps=12, seed=6)
+    a = U.UAVVecEnv(E, n_stack=k, **kw)
+    b = U.UAVVecEnv(E, **kw)
+    D = b.observation_space.shape[0]
+    assert a.observation_space.shape == (k * D,)
+    oa, ob = a.reset(), b.reset()
+    ref = np.zeros((E, k * D), np.float32); ref[:, -D:] = ob
+    assert np.array_equal(oa, ref)
+    rng = np.random.default_rng(0)
+    for s in range(40):
+        acts = rng.integers(0, 5, size=E)
+        oa, ra, da, ia = a.step(acts)
+        ob, rb, db, ib = b.step(acts)
+        term = np.zeros((E, D), np.float32)
+        for i in np.nonzero(db)[0]:
+            term[i] = ib[i]["terminal_observation"]
+        ref, terminal = _sb3_frame_stack_step(ref, ob, db, term, D)
+        assert np.array_equal(oa, ref) and np.array_equal(ra, rb) and np.array_equal(da, db)
+        for i, row in terminal.items():
+            assert np.array_equal(ia[i]["terminal_observation"], row)
+    a.close(); b.close()
