@@ -161,7 +161,8 @@ int uavenv_lane_stride(const UavEnv* env);
 int uavenv_env_obs_dim(const UavEnv* env);
 
 /* ---- per-environment parameters (BASELINE config 5: mixed grid / sensor-count sweeps) ------- */
-/* host arrays of num_envs entries, each nullable; takes effect at the next reset of each env */
+/* host arrays of num_envs entries, each nullable; take effect immediately (call before uavenv_reset);
+ * num_sensors[i] must be in 1..cfg.num_sensors (the observation keeps cfg.num_sensors slots, zero padded) */
 int uavenv_set_env_params(UavEnv* env, const int32_t* grid_w, const int32_t* grid_h, const int32_t* num_sensors);
 /* replaces: the sensor_positions kwarg (uav_env.py:269); host float [E][stride] */
 int uavenv_set_positions(UavEnv* env, const float* pos_x, const float* pos_y);
@@ -206,8 +207,8 @@ int uavenv_step_policy(UavEnv* env, int32_t policy, int32_t* actions_out_dev, fl
                        float* reward32_out_dev, uint8_t* done_out_dev, float* terminal_obs_dev, void* stream);
 
 /* K consecutive steps in ONE launch (SURVEY 8b "uavenv_step_k"): policy UAVENV_POLICY_ACTIONS = open-loop
- * actions (actions_dev int32 [K][E]), otherwise an in-kernel policy (random or heuristic).  Sensor state stays in
- * registers and the record in LDS for the whole launch, but EVERY step still writes its block:
+ * actions (actions_dev int32 [K][E]), otherwise an in-kernel policy (random or heuristic).  Sensor state and the
+ * per-environment record stay in registers for the whole launch, but EVERY step still writes its block:
  * obs_out_dev [K][E][obs_dim], reward [K][E], done [K][E], actions_out [K][E] (each nullable), e.g. K
  * consecutive slots of a replay ring.  Bit-identical to K uavenv_step / uavenv_step_random launches.
  * replaces: the `for _ in range(K): env.step(policy(obs))` loop of uav_env.py:935-960 / SB3
