@@ -9,11 +9,12 @@ this package is the Python host side that mirrors the reference's gymnasium / SB
 from . import _native
 from ._native import (FLAG_AUTO_RESET, FLAG_FAR_START, FLAG_JAIN_BONUS, FLAG_PROX_SHAPING, FLAG_RANDOM_LAYOUT,
                       UavEnvConfig, UavEnvError, default_config)
+from .attention import FusedAttentionFeatures, pack_attention_weights
 from .batched_env import BatchedUAVEnv, config_from_kwargs
 from .frame_stack import FrameStack
 from .gym_env import CURRICULUM_STAGES, DomainRandEnv, UAVEnvironment
 from .replay import TransitionRing
 from .vec_env import UAVVecEnv
 
-__all__ = ["BatchedUAVEnv", "UAVEnvironment", "DomainRandEnv", "UAVVecEnv", "TransitionRing", "FrameStack", "CURRICULUM_STAGES", "UavEnvConfig", "UavEnvError", "default_config", "config_from_kwargs",
+__all__ = ["BatchedUAVEnv", "UAVEnvironment", "DomainRandEnv", "UAVVecEnv", "TransitionRing", "FrameStack", "FusedAttentionFeatures", "pack_attention_weights", "CURRICULUM_STAGES", "UavEnvConfig", "UavEnvError", "default_config", "config_from_kwargs",
            "FLAG_AUTO_RESET", "FLAG_FAR_START", "FLAG_JAIN_BONUS", "FLAG_PROX_SHAPING", "FLAG_RANDOM_LAYOUT"]

@@ -10,7 +10,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libuavenv_hip.so")
-SOURCES = ["uavenv_kernels.hip", "uavenv_capi.hip"]
+SOURCES = ["uavenv_kernels.hip", "uavenv_capi.hip", "uavenv_attention.hip"]
 HEADERS = ["uavenv_internal.h", "uavenv_noise.h", os.path.join("..", "..", "include", "uavenv.h")]
 # -ffp-contract=off: the float64 state has to follow the reference's (numpy, unfused) operation order.
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall", "-Wno-bitwise-instead-of-logical"]

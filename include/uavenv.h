@@ -239,6 +239,15 @@ int uavenv_set_aux_output(UavEnv* env, float* aux_out_dev);
 int uavenv_frame_stack(float* stacked_dev, const float* obs_dev, const uint8_t* done_dev, const float* terminal_obs_dev,
                        float* terminal_stacked_dev, int32_t num_envs, int32_t num_frames, int32_t obs_dim, void* stream);
 
+/* ---- the consumer of the observation layout: UAVAttentionExtractor forward (dqn.py:548-650) ------------- */
+/* replaces: UAVAttentionExtractor.forward for inference, fused into one launch.  obs_dev float
+ * [batch][n_stack*153] (the frame-stacked, 50-slot padded observation), weights_dev = the extractor's parameters
+ * packed as uavenv_attention_weight_floats(n_stack) floats (order and transposes: csrc/uavenv_attention.hip
+ * `Offsets`; uavenv_amd/attention.py packs a torch state_dict), out_dev float [batch][128].  Needs no UavEnv. */
+int uavenv_attention_weight_floats(int32_t n_stack);
+int uavenv_attention_features(const float* obs_dev, const float* weights_dev, float* out_dev, int32_t batch,
+                              int32_t n_stack, void* stream);
+
 /* ---- state access (checkpoint / parity / the attribute reads of SURVEY 1) -------------------- */
 /* Copies one whole field.  `bytes` must equal the field size; dst/src may be host or device. */
 int uavenv_get_state(UavEnv* env, int32_t field, void* dst, size_t bytes, int32_t dst_on_device, void* stream);

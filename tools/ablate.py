@@ -17,7 +17,7 @@ for name, flags in VARIANTS:
     lib = os.path.join(OUT, f"lib_{name}.so")
     procs.append((name, lib, subprocess.Popen(
         ["hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"] + flags +
-        ["-o", lib, os.path.join(PKG, "csrc", "uavenv_kernels.hip"), os.path.join(PKG, "csrc", "uavenv_capi.hip")])))
+        ["-o", lib, os.path.join(PKG, "csrc", "uavenv_kernels.hip"), os.path.join(PKG, "csrc", "uavenv_capi.hip"), os.path.join(PKG, "csrc", "uavenv_attention.hip")])))
 for name, lib, p in procs:
     assert p.wait() == 0, name
 child = r'''
