@@ -54,7 +54,17 @@ def cpu_baseline(num_sensors, grid, seconds_target=12.0):
     t0 = time.perf_counter()
     n, _ = O.run_random_policy(cfg, envs, steps)
     dt = time.perf_counter() - t0
+    # the same port on P host threads over disjoint environment shards (ctypes releases the GIL), P = the box's
+    # CPU share for one GPU (16) or fewer; reported beside the single-core figure, never instead of it
+    from concurrent.futures import ThreadPoolExecutor
+    P = max(1, min(16, os.cpu_count() or 1))
+    psteps = max(50, steps // 3)
+    t1 = time.perf_counter()
+    with ThreadPoolExecutor(P) as ex:
+        res = list(ex.map(lambda k: O.run_random_policy(cfg, envs, psteps, env_index_base=k * envs)[0], range(P)))
+    dtp = time.perf_counter() - t1
     return {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "all_cores": {"value": sum(res) / dtp, "cores": P, "sample": f"{P} threads x {envs} envs x {psteps} vector steps"},
             "sample": f"first {envs} of the 4096 envs x {num_sensors} sensors, {steps} vector steps "
                       f"({n} env-steps, {dt:.1f} s), oracle/uavenv_oracle.c, 1 thread",
             "reference_python_1core_survey": {"n20": 1692, "n50": 764, "unit": "env-steps/s",
@@ -114,10 +124,29 @@ def main():
     exchange = args.exchange
     if exchange == "auto":
         exchange = "allgather" if distributed else "none"
+    if not distributed:
+        exchange = "none"
     ring = TransitionRing(args.ring, E, env.obs_dim, dev, world_size=world if exchange == "allgather" else 1,
                           rank=rank if exchange == "allgather" else 0)
     ring.attach(env)      # the kernel writes obs AND (action, reward, done, terminal row) straight into the ring slot
     env.reset()
+    exchange_error = None
+    if exchange == "allgather":
+        # One probe exchange before anything is timed: if the collective cannot run on this node, say so in the
+        # JSON line and measure the shards without it rather than dying without a result.
+        try:
+            env.step_random(obs_out=ring.local_obs_slot())
+            ring.commit()
+            ring.drain()
+            torch.cuda.synchronize(dev)
+        except Exception as ex:          # pragma: no cover - depends on the node
+            exchange_error = repr(ex)[:300]
+        flag = torch.tensor([1 if exchange_error else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            exchange = "none"
+            ring = TransitionRing(args.ring, E, env.obs_dim, dev, world_size=1, rank=0)
+            ring.attach(env)
 
     def one_step():
         env.step_random(obs_out=ring.local_obs_slot())
@@ -204,6 +233,8 @@ def main():
     }
     if fused:
         out["fused_rollout"] = fused
+    if distributed and exchange_error:
+        out["config"]["exchange_error"] = exchange_error
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n, (args.grid, args.grid))
         out["cpu_baseline"]["host"] = {"cpu_count": os.cpu_count()}

@@ -482,3 +482,35 @@ def test_mixed_grid_and_sensor_count_in_one_handle():
                 oo = orcs[k].reset_keyed()
             assert np.max(np.abs(o[k] - oo)) <= OBS_ATOL and _rel(r[k], rr) <= REW_RTOL and bool(d[k]) == tr, (s, k)
     env.close()
+
+
+EXOTIC = [
+    dict(use_ema_adr=0, duty_cycle=60.0),                                   # iot_sensors.py:245 non-EMA branch
+    dict(data_generation_rate=0.0, duty_cycle=80.0, fill_lo=0.5, fill_hi=0.9),   # rate 0: AoI urgency branch uav_env.py:390-393
+    dict(collection_duration=3.0, duty_cycle=100.0, power_hover=900.0, power_move=350.0),
+    dict(fill_lo=0.9, fill_hi=1.4, duty_cycle=100.0, max_buffer_size=300.0),     # np.clip(fill, 0, 1) at iot_sensors.py:308
+    dict(sf_thresholds=[-50.0, -64.0, -75.0, -90.0], rssi_threshold=-92.0, capture_threshold_db=1.5, duty_cycle=100.0,
+         shadowing_std_db=7.0, noise_floor_dbm=-100.0),
+    dict(alive_fraction=0.6, duty_cycle=50.0, penalty_unvisited=-77.0, penalty_starved=-13.0, starvation_cr_threshold=0.6),
+    dict(capture_threshold_db=-3.0, duty_cycle=100.0),                      # negative margin: the strongest always captures
+    dict(uav_altitude=30.0, sensor_height=1.5, wavelength=0.125, freq_mhz=2400.0, tx_power_dbm=20.0, duty_cycle=70.0),
+]
+
+
+@pytest.mark.parametrize("idx", range(len(EXOTIC)))
+def test_exotic_configurations_match_oracle(idx):
+    """Every constant of the path is a runtime parameter: unusual values of the IoTSensor / UAV /
+    reward parameters, HIP vs oracle (no reference fixture reaches these through the env's kwargs)."""
+    torch, U, O = _mods()
+    E, steps, seed = 32, 140, 900 + idx
+    over = dict(num_sensors=20, grid_size=(140, 140), max_steps=45, **EXOTIC[idx])
+    want = O.trace_keyed(O.default_config(seed=seed, **over), E, steps)
+    env = U.BatchedUAVEnv(E, seed=seed, **over)
+    assert np.array_equal(env.reset().cpu().numpy(), want["reset_obs"])
+    ro = env.rollout(steps, with_terminal=True)
+    assert np.array_equal(ro["done"].cpu().numpy(), want["done"])
+    assert np.array_equal(ro["actions"].cpu().numpy(), want["actions"])
+    assert np.max(np.abs(ro["obs"].cpu().numpy() - want["obs"])) <= OBS_ATOL
+    assert np.max(_rel(ro["reward"].cpu().numpy(), want["reward"])) <= REW_RTOL
+    assert want["done"].any() and np.isfinite(want["reward"]).all()
+    env.close()
