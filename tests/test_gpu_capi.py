@@ -1,0 +1,85 @@
+"""GPU: the C ABI used from a plain-C program (no Python/torch in the process), HIP-graph capture of the step,
+and handle lifetime."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "-reinforcement-learning-for-dynamic-uav-energy-efficient-path-planning-in-iot-sensor-networks._amd")
+
+
+def test_plain_c_program_through_the_abi(tmp_path):
+    import torch
+    import uavenv_amd as U
+    exe = str(tmp_path / "capi_demo")
+    subprocess.check_call(["gcc", "-O1", "-std=c11", "-I", os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(ROOT, "tests", "capi", "capi_demo.c"), "-L", PKG, "-luavenv_hip",
+                           "-Wl,-rpath," + PKG])
+    out = subprocess.check_output([exe, "8", "25"], text=True)
+    m = re.search(r"obs_dim=(\d+) reward_sum=([-\d.]+) obs_sum=([-\d.]+) dones=(\d+) invalid_rc=(-?\d+)", out)
+    assert m, out
+    E, steps = 8, 25
+    env = U.BatchedUAVEnv(E, num_sensors=20, grid_size=(200, 200), max_steps=10, duty_cycle=60.0, seed=99)
+    env.reset()
+    total, dones = 0.0, 0
+    for s in range(steps):
+        a = torch.tensor([(s * 7 + k * 3) % 5 for k in range(E)], dtype=torch.int32, device=env.device)
+        o, r, d = env.step(a)
+        total += float(r.sum().item()); dones += int(d.sum().item())
+    assert int(m.group(1)) == env.obs_dim and int(m.group(4)) == dones and dones >= 2 * E - 8
+    assert abs(float(m.group(2)) - total) <= 1e-6 * max(1.0, abs(total))
+    assert abs(float(m.group(3)) - float(o.double().sum().item())) <= 1e-3
+    assert int(m.group(5)) == -3                                  # UAVENV_E_ACTION
+    env.close()
+
+
+def test_step_is_hip_graph_capturable():
+    """No allocation / synchronisation inside the launch path: the step can be captured into a HIP graph and
+    replayed (cdna_hip_programming.md guideline 9); replays advance the environment exactly like eager steps."""
+    import torch
+    import uavenv_amd as U
+    kw = dict(num_sensors=50, seed=17, max_steps=40)
+    a, b = U.BatchedUAVEnv(256, **kw), U.BatchedUAVEnv(256, **kw)
+    a.reset(); b.reset()
+    for _ in range(3):
+        a.step_random(); b.step_random()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(4):
+            a.step_random()
+    for _ in range(4):                 # the capture itself did not execute: the eager twin does its 4 steps
+        b.step_random()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(a.obs, b.obs) and torch.equal(a.reward, b.reward)
+    for rep in range(5):
+        g.replay()
+        for _ in range(4):
+            b.step_random()
+    torch.cuda.synchronize()
+    assert torch.equal(a.obs, b.obs) and torch.equal(a.reward, b.reward) and torch.equal(a.done, b.done)
+    sa, sb = a.state_dict(), b.state_dict()
+    assert all(torch.equal(sa[k], sb[k]) for k in sa)
+    a.close(); b.close()
+
+
+def test_many_handles_create_destroy():
+    import torch
+    import uavenv_amd as U
+    free0 = torch.cuda.mem_get_info()[0]
+    envs = [U.BatchedUAVEnv(512, num_sensors=n, seed=i) for i, n in enumerate((10, 20, 50, 64, 1))]
+    outs = []
+    for e in envs:
+        e.reset(); e.step_random(); outs.append(e.reward.sum().item())
+    assert all(np.isfinite(outs))
+    for e in envs:
+        e.close()
+    for _ in range(30):
+        e = U.BatchedUAVEnv(2048, num_sensors=50); e.reset(); e.step_random(); e.close()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)      # no leak beyond allocator slack
