@@ -135,6 +135,7 @@ static void derive_consts(const UavEnvConfig& c, Consts& k) {
     k.min_start_dist = c.min_start_dist; k.prox_eta = c.prox_eta; k.jain_weight = c.jain_weight;
     k.alt2 = (float)(c.uav_altitude * c.uav_altitude);                   // iot_sensors.py:164
     k.max_steps = c.max_steps; k.fps = c.include_sensor_positions ? 5 : 3; k.obs_dim = obs_dim_of(&c);
+    k.obs_slots = (k.obs_dim - 3) / k.fps;
     k.max_tries = c.max_start_tries; k.use_ema = c.use_ema_adr; k.n_grid_choices = c.num_grid_choices;
     k.flags = c.flags;
     for (int i = 0; i < 8; i++) { k.gw[i] = c.grid_choices_w[i]; k.gh[i] = c.grid_choices_h[i]; }
@@ -186,9 +187,6 @@ extern "C" int uavenv_create(const UavEnvConfig* cfg, int32_t num_envs, uint32_t
     const int per_block = kBlockThreads / e->G;
     e->padded_envs = ((num_envs + per_block - 1) / per_block) * per_block;
     derive_consts(e->cfg, e->consts);
-    if ((size_t)per_block * (size_t)e->consts.obs_dim * sizeof(float) > 64 * 1024) {
-        delete e; return fail(nullptr, UAVENV_E_INVALID, "observation row too large for the LDS staging tile");
-    }
     auto bail = [&](int code, const std::string& m) { uavenv_destroy(e); return fail(nullptr, code, m); };
     hipError_t st = hipSetDevice(device);
     if (st != hipSuccess) return bail(UAVENV_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(st));

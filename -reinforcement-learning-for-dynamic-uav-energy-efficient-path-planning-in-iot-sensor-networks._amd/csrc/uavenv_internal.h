@@ -8,7 +8,13 @@
 
 namespace uavenv {
 
-constexpr int kBlockThreads = 256;          // 4 wavefronts per workgroup
+#ifndef UAV_BLOCK
+#define UAV_BLOCK 256
+#endif
+#ifndef UAV_LDS_PAD       // dev-only occupancy cap for launch-shape experiments (tools/ablate.py)
+#define UAV_LDS_PAD 0
+#endif
+constexpr int kBlockThreads = UAV_BLOCK;    // 4 wavefronts per workgroup
 
 // flag word per sensor (UAVENV_F_FLAGS)
 constexpr uint32_t kSfMask = 15u, kAvgValid = 16u, kVisited = 32u, kDataCollected = 64u;
@@ -33,7 +39,7 @@ struct Consts {
     double e_move, e_coll; // uav.py:176,180      (P*t)/3600
     double p_step, r_move, p_boundary, p_battery, p_loss;
     float  alt2;           // iot_sensors.py:164  altitude**2 as float32
-    int32_t max_steps, fps, obs_dim, use_ema;
+    int32_t max_steps, fps, obs_dim, obs_slots, use_ema;
     uint32_t flags;
     // ---- collect steps -----------------------------------------------------------------------
     double coll_dur, p_cycle, noise_floor, cap_thr;

@@ -351,14 +351,16 @@ template <int G> __device__ __forceinline__ double jains_index(const Sensor& s, 
 }
 
 // uav_env.py:638-674 _get_observation for one environment group.  SIDE EFFECT on the lane's
-// sensor: advances the ADR EMA with slot zD, then draws the in-range sample zE.  The row is staged
-// in LDS (stride-fps writes are bank-conflict free: fps in {3,5} is coprime to 32) and written
-// out as contiguous dwords.  `enable` masks whole groups (a wave may hold groups that do not
-// rebuild); `dst` may be nullptr (row computed for its side effects, not stored).
+// sensor: advances the ADR EMA with slot zD, then draws the in-range sample zE.  Each lane stores its own
+// sensor's fps consecutive floats (one global_store_dwordx3 when fps = 3): the lanes of a group cover the row
+// contiguously, so the stores coalesce without staging the row anywhere.  `enable` masks whole groups (a
+// wave may hold groups that do not rebuild); `dst` may be nullptr (row computed for its side effects only).
+struct __attribute__((packed, aligned(4))) ObsF3 { float a, b, c; };
+struct __attribute__((packed, aligned(4))) ObsF2 { float a, b; };
 template <int G, bool kLean>
 __device__ __forceinline__ void observe(CRef c, Sensor& s, int n, int gw, int gh, double inv_w, double inv_h,
                                         float uxf, float uyf, double battery, bool act, bool enable,
-                                        double det, float zD, float zE, float* dst, float* lds_row) {
+                                        double det, float zD, float zE, float* dst) {
     const int gl = group_lane<G>();
     double W = (double)gw, H = (double)gh;
     double ux = (double)uxf, uy = (double)uyf;
@@ -375,31 +377,26 @@ __device__ __forceinline__ void observe(CRef c, Sensor& s, int n, int gw, int gh
             f4 = (float)div_const((double)s.sy - uy, H, inv_h);
         }
     }
-    if (enable) {
-        // zero the padded tail [3 + fps*n, obs_dim)  (dqn.py:286-298)
-        for (int k = 3 + UAV_FPS(c) * n + gl; k < c.obs_dim; k += G) lds_row[k] = 0.0f;
+    if (enable && dst != nullptr) {
         if (gl == 0) {
-            lds_row[0] = (float)div_const(ux, W, inv_w);
-            lds_row[1] = (float)div_const(uy, H, inv_h);
-            lds_row[2] = (float)div_const(battery, c.maxb, c.inv_maxb);
+            ObsF3 h;
+            h.a = (float)div_const(ux, W, inv_w);
+            h.b = (float)div_const(uy, H, inv_h);
+            h.c = (float)div_const(battery, c.maxb, c.inv_maxb);
+            *reinterpret_cast<ObsF3*>(dst) = h;
         }
-        if (act) {
-            float* q = lds_row + 3 + UAV_FPS(c) * gl;
-            q[0] = f0; q[1] = f1; q[2] = f2;
-            if (UAV_FPS(c) == 5) { q[3] = f3; q[4] = f4; }
+        // slot gl holds this lane's sensor (zeros beyond n: the padded tail of dqn.py:286-298); groups narrower
+        // than the padded row (num_sensors <= 32 padded to 50) zero the remaining slots in further passes
+        const int slots = c.obs_slots;
+        const int fps = UAV_FPS(c);
+        for (int k = gl; k < slots; k += G) {
+            const bool own = k == gl;
+            float* q = dst + 3 + fps * k;
+            ObsF3 v; v.a = own ? f0 : 0.f; v.b = own ? f1 : 0.f; v.c = own ? f2 : 0.f;
+            *reinterpret_cast<ObsF3*>(q) = v;
+            if (fps == 5) { ObsF2 w; w.a = own ? f3 : 0.f; w.b = own ? f4 : 0.f; *reinterpret_cast<ObsF2*>(q + 3) = w; }
         }
     }
-    // LDS hand-off inside one wavefront: wave-scope release/acquire is sufficient (and a workgroup
-    // barrier would be illegal here: the second observe() of a step runs under wave-uniform, not
-    // workgroup-uniform, control flow).
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (enable && dst != nullptr)
-        for (int k = gl; k < c.obs_dim; k += G) dst[k] = lds_row[k];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // Noise for one step of one lane: Philox, or the injected tape (parity testing).  zC (the range check of
@@ -620,11 +617,9 @@ template <int G>
 __global__ __launch_bounds__(kBlockThreads) void uav_reset_kernel(const Consts* cptr, Ptrs p, ResetArgs a) {
     constexpr bool kLean = false;
     UAV_CONSTS(cptr);
-    extern __shared__ float lds[];
     const int gl = group_lane<G>();
     const uint32_t env = blockIdx.x * (kBlockThreads / G) + threadIdx.x / G;
     const uint32_t idx = env * G + gl;
-    float* lds_row = lds + (threadIdx.x / G) * c.obs_dim;
 
     UavEnvRecord r = p.rec[env];
     Sensor s;
@@ -641,7 +636,7 @@ __global__ __launch_bounds__(kBlockThreads) void uav_reset_kernel(const Consts* 
     if (rs) { r.uav_x = r.start_x; r.uav_y = r.start_y; }                         // uav.py:256, dqn.py:364-365
     double det = rssi_deterministic(c, r.uav_x, r.uav_y, s.sx, s.sy);
     float* dst = (in_batch && a.obs != nullptr) ? a.obs + env * (size_t)c.obs_dim : nullptr;
-    observe<G, kLean>(c, s, r.num_sensors, r.grid_w, r.grid_h, r.inv_grid_w, r.inv_grid_h, r.uav_x, r.uav_y, r.battery, act, rs, det, zD, zE, dst, lds_row);   // uav_env.py:427
+    observe<G, kLean>(c, s, r.num_sensors, r.grid_w, r.grid_h, r.inv_grid_w, r.inv_grid_h, r.uav_x, r.uav_y, r.battery, act, rs, det, zD, zE, dst);   // uav_env.py:427
     if (UAV_FLAGS(c) & UAVENV_FLAG_PROX_SHAPING) {
         double d0 = dist_nearest_with_data<G>(s, act, r.uav_x, r.uav_y);           // dqn.py:368
         if (rs) r.prev_dist_nearest = d0;
@@ -659,7 +654,7 @@ __global__ __launch_bounds__(kBlockThreads) void uav_reset_kernel(const Consts* 
 // ---------------------------------------------------------------------------------------------
 template <int G, bool kLean, bool kRegs = false, typename RecPtr = UavEnvRecord*>
 __device__ __forceinline__ void step_once(CRef c, const Ptrs& p, const StepArgs& a, uint32_t env, bool in_batch,
-                                          float* lds_row, RecPtr rec, Sensor& s, bool& wrote_pos, uint32_t& status_or,
+                                          RecPtr rec, Sensor& s, bool& wrote_pos, uint32_t& status_or,
                                           int& action_out) {
     const int gl = group_lane<G>();
     Env e = load_env<G>(rec);
@@ -906,7 +901,7 @@ __device__ __forceinline__ void step_once(CRef c, const Ptrs& p, const StepArgs&
             if (in_batch && gl == 0 && a.term_index != nullptr) a.term_index[env] = row;
             term_row = row;
         }
-        observe<G, kLean>(c, s, n, e.gw, e.gh, e.inv_w, e.inv_h, e.ux, e.uy, e.battery, act, true, det, z.zD, z.zE, dst, lds_row);   // :488
+        observe<G, kLean>(c, s, n, e.gw, e.gh, e.inv_w, e.inv_h, e.ux, e.uy, e.battery, act, true, det, z.zD, z.zE, dst);   // :488
     }
 
     // ---- epilogue: the cold part of the record (read late on purpose: see struct Env) -----------------
@@ -976,7 +971,7 @@ __device__ __forceinline__ void step_once(CRef c, const Ptrs& p, const StepArgs&
         if (do_reset) { r.uav_x = r.start_x; r.uav_y = r.start_y; }
         double det0 = rssi_deterministic(c, r.uav_x, r.uav_y, s.sx, s.sy);
         float* dst = (in_batch && a.obs) ? a.obs + env * (size_t)c.obs_dim : nullptr;
-        observe<G, kLean>(c, s, r.num_sensors, r.grid_w, r.grid_h, r.inv_grid_w, r.inv_grid_h, r.uav_x, r.uav_y, r.battery, act, do_reset, det0, zD, zE, dst, lds_row);
+        observe<G, kLean>(c, s, r.num_sensors, r.grid_w, r.grid_h, r.inv_grid_w, r.inv_grid_h, r.uav_x, r.uav_y, r.battery, act, do_reset, det0, zD, zE, dst);
         if (UAV_FLAGS(c) & UAVENV_FLAG_PROX_SHAPING) {
             double d0 = dist_nearest_with_data<G>(s, act, r.uav_x, r.uav_y);
             if (do_reset) r.prev_dist_nearest = d0;
@@ -995,21 +990,19 @@ __device__ __forceinline__ void step_once(CRef c, const Ptrs& p, const StepArgs&
 template <int G, bool kLean>
 __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_kernel(const Consts* cptr, Ptrs p, StepArgs a) {
     UAV_CONSTS(cptr);
-    extern __shared__ float lds[];
 #ifdef UAVENV_STAMPS
     const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const int gl = group_lane<G>();
     const uint32_t env = blockIdx.x * (kBlockThreads / G) + uni<G>((int)(threadIdx.x / G));
     const uint32_t idx = env * G + gl;
-    float* lds_row = lds + (threadIdx.x / G) * c.obs_dim;
     const bool in_batch = env < (uint32_t)a.num_envs;
     Sensor s;
     load_sensor<G>(p, idx, s);
     bool wrote_pos = false;
     uint32_t status_or = 0u;
     int action = 0;
-    step_once<G, kLean>(c, p, a, env, in_batch, lds_row, p.rec + env, s, wrote_pos, status_or, action);
+    step_once<G, kLean>(c, p, a, env, in_batch, p.rec + env, s, wrote_pos, status_or, action);
     store_sensor<G>(p, idx, s, wrote_pos);
     if (gl == 0 && status_or) atomicOr(p.status, status_or);
 #ifdef UAVENV_STAMPS
@@ -1033,12 +1026,10 @@ template <int G, bool kLean>
 __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_rollout_kernel(const Consts* cptr, Ptrs p, StepArgs a,
                                                                                      int32_t num_steps) {
     UAV_CONSTS(cptr);
-    extern __shared__ float lds[];
     const int gl = group_lane<G>();
     const uint32_t grp = threadIdx.x / G;
     const uint32_t env = blockIdx.x * (kBlockThreads / G) + uni<G>((int)grp);
     const uint32_t idx = env * G + gl;
-    float* lds_row = lds + grp * c.obs_dim;
     const bool in_batch = env < (uint32_t)a.num_envs;
     Sensor s;
     load_sensor<G>(p, idx, s);
@@ -1063,7 +1054,7 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_rollout_
         const Consts* cp = cptr;
         asm volatile("" : "+s"(cp));
         CRef ck = *(const __attribute__((address_space(4))) Consts*)(cp);
-        step_once<G, kLean, true>(ck, p, ak, env, in_batch, lds_row, &rr, s, wrote_pos, status_or, action);
+        step_once<G, kLean, true>(ck, p, ak, env, in_batch, &rr, s, wrote_pos, status_or, action);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1154,7 +1145,7 @@ __global__ __launch_bounds__(kBlockThreads) void uav_frame_stack_kernel(float* s
 hipError_t launch_frame_stack(float* stacked, const float* obs, const uint8_t* done, const float* terminal_obs,
                               float* terminal_stacked, int32_t num_envs, int32_t k, int32_t D, hipStream_t s) {
     if (k < 1 || D < 1 || (long long)k * D > 64LL * kFsMaxPerLane) return hipErrorInvalidValue;
-    dim3 block(kBlockThreads), grid((unsigned)((num_envs + 3) / 4));
+    dim3 block(kBlockThreads), grid((unsigned)((num_envs + kBlockThreads / 64 - 1) / (kBlockThreads / 64)));
     uav_frame_stack_kernel<<<grid, block, 0, s>>>(stacked, obs, done, terminal_obs, terminal_stacked, num_envs, k, D);
     return hipGetLastError();
 }
@@ -1167,7 +1158,7 @@ static inline bool lean_ok(const Consts& c, const Ptrs& p, const StepArgs& a) {
     return (c.flags & ~(uint32_t)UAVENV_FLAG_AUTO_RESET) == 0u && c.fps == 3 && p.step_tape == nullptr &&
            p.reset_tape == nullptr && a.policy <= UAVENV_POLICY_RANDOM;
 }
-static inline size_t lds_bytes(int G, const Consts& c) { return (size_t)(kBlockThreads / G) * (size_t)c.obs_dim * sizeof(float); }
+static inline size_t lds_bytes(int, const Consts&) { return UAV_LDS_PAD; }     // no LDS: 0 unless a dev build caps occupancy
 
 #define UAV_DISPATCH_G(G_, CALL)          \
     switch (G_) {                         \

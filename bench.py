@@ -63,7 +63,15 @@ def cpu_baseline(num_sensors, grid, seconds_target=12.0):
     with ThreadPoolExecutor(P) as ex:
         res = list(ex.map(lambda k: O.run_random_policy(cfg, envs, psteps, env_index_base=k * envs)[0], range(P)))
     dtp = time.perf_counter() - t1
-    return {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port", "cpu_model": model,
             "all_cores": {"value": sum(res) / dtp, "cores": P, "sample": f"{P} threads x {envs} envs x {psteps} vector steps"},
             "sample": f"first {envs} of the 4096 envs x {num_sensors} sensors, {steps} vector steps "
                       f"({n} env-steps, {dt:.1f} s), oracle/uavenv_oracle.c, 1 thread",
