@@ -79,7 +79,24 @@ UAV_HD uint32_t float_to_bits(float f) {
 // Correctly rounded float32 square root on both sides.  NOTE: on gfx950 `__fsqrt_rn` lowers to a bare
 // v_sqrt_f32 (1 ulp); `__builtin_sqrtf` gets the fma fix-up sequence and IS correctly rounded (hipcc's
 // default -fhip-fp32-correctly-rounded-divide-sqrt), which numpy's float32 sqrt requires.
-UAV_HD float sqrt_rn(float x) { return __builtin_sqrtf(x); }
+// On the device the generic expansion also rescales denormal inputs and patches 0/inf with a class test (17
+// VALU instructions); this path only ever takes the root of 0 or of normal numbers far from the range ends, so
+// `sqrt_rn` keeps the part that matters (9 instructions): the hardware estimate (<= 1 ulp) and the exact-residual
+// choice between it and its two neighbours.  tools/check_sqrt.hip compares it with __builtin_sqrtf over every
+// float: 0 mismatches for x in {0} U [2^-104, 2^127] (below that the residuals underflow; the path's arguments
+// are 0 or lie in [1e-8, 1e12]).
+UAV_HD float sqrt_rn(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(UAV_ABL_LIBSQRT)
+    const float y = __builtin_amdgcn_sqrtf(x);
+    const float y_dn = __uint_as_float(__float_as_uint(y) - 1u), y_up = __uint_as_float(__float_as_uint(y) + 1u);
+    const float r_dn = __builtin_fmaf(-y_dn, y, x), r_up = __builtin_fmaf(-y_up, y, x);
+    float r = r_dn <= 0.0f ? y_dn : y;        // x = 0: y_dn is a NaN pattern, the comparison is false
+    r = r_up > 0.0f ? y_up : r;
+    return r;
+#else
+    return __builtin_sqrtf(x);
+#endif
+}
 
 // Two standard normals from two 32-bit words.
 //   radius: u1 = ((a>>8)+1) * 2^-24 in (0,1];  -ln u1 by exponent split + degree-9 minimax polynomial
