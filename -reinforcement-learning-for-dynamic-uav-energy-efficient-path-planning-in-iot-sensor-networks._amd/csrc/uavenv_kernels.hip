@@ -190,7 +190,7 @@ __device__ __forceinline__ float sf_link_quality_f32(uint32_t sf) {
 }
 
 // log10 of a positive normal float32, evaluated in float64 and rounded once to float32.
-// Specification shared with the oracle (oracle/uavenv_oracle.c:orc_log10_f32), IEEE + - * / only:
+// Specification shared with the oracle (oracle/uavenv_oracle.c:orc_log10_f32), IEEE + - * / fma only:
 // x = m * 2^e with m folded into [sqrt(1/2), sqrt(2)); ln m = 2 atanh(s), s = (m-1)/(m+1), by the odd
 // series to s^17 (|s| <= 0.172 -> truncation 8e-16); result = e*log10(2) + ln(m)*log10(e).
 // Absolute error ~1e-15, i.e. the correctly rounded float32 log10 except with probability ~1e-8.
@@ -205,16 +205,16 @@ __device__ __forceinline__ float log10_f32(float d) {
     double s = (m - 1.0) / (m + 1.0);
     double s2 = s * s;
     double p = 1.0 / 17;
-    p = p * s2 + 1.0 / 15;
-    p = p * s2 + 1.0 / 13;
-    p = p * s2 + 1.0 / 11;
-    p = p * s2 + 1.0 / 9;
-    p = p * s2 + 1.0 / 7;
-    p = p * s2 + 1.0 / 5;
-    p = p * s2 + 1.0 / 3;
+    p = __builtin_fma(p, s2, 1.0 / 15);
+    p = __builtin_fma(p, s2, 1.0 / 13);
+    p = __builtin_fma(p, s2, 1.0 / 11);
+    p = __builtin_fma(p, s2, 1.0 / 9);
+    p = __builtin_fma(p, s2, 1.0 / 7);
+    p = __builtin_fma(p, s2, 1.0 / 5);
+    p = __builtin_fma(p, s2, 1.0 / 3);
     double t = 2.0 * s;
-    double ln_m = t + t * (s2 * p);
-    double r = (double)e * 0.30102999566398120 + ln_m * 0.43429448190325182;
+    double ln_m = __builtin_fma(t, s2 * p, t);
+    double r = __builtin_fma((double)e, 0.30102999566398120, ln_m * 0.43429448190325182);
     return (float)r;
 }
 

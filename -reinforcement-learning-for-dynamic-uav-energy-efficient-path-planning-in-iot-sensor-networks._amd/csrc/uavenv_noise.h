@@ -14,7 +14,7 @@
 //   call 4 (lane field = try):   w0,w1 -> far-start candidate
 //
 // Normals come from a Box-Muller transform written WITHOUT transcendental instructions: only IEEE
-// float32 +,-,*,sqrt and integer ops in a fixed order, compiled with -ffp-contract=off, so the
+// float32 +,-,*,fma,sqrt and integer ops in a fixed order, compiled with -ffp-contract=off, so the
 // device and any IEEE host produce bit-identical values (the CPU oracle restates the same
 // specification independently in oracle/uavenv_oracle.c).
 #pragma once
@@ -98,6 +98,9 @@ UAV_HD float sqrt_rn(float x) {
 #endif
 }
 
+// IEEE fused multiply-add (one rounding), explicit: the file is compiled with -ffp-contract=off, so nothing else fuses.
+UAV_HD float fma32(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 // Two standard normals from two 32-bit words.
 //   radius: u1 = ((a>>8)+1) * 2^-24 in (0,1];  -ln u1 by exponent split + degree-9 minimax polynomial
 //           on the mantissa folded into [sqrt(1/2), sqrt(2));
@@ -116,17 +119,17 @@ UAV_HD void normal_pair(uint32_t a, uint32_t b, float& z0, float& z1) {
     float t = m - 1.0f;
     float z = t * t;
     float p = 7.0376836292E-2f;
-    p = p * t + -1.1514610310E-1f;
-    p = p * t + 1.1676998740E-1f;
-    p = p * t + -1.2420140846E-1f;
-    p = p * t + 1.4249322787E-1f;
-    p = p * t + -1.6668057665E-1f;
-    p = p * t + 2.0000714765E-1f;
-    p = p * t + -2.4999993993E-1f;
-    p = p * t + 3.3333331174E-1f;
+    p = fma32(p, t, -1.1514610310E-1f);
+    p = fma32(p, t, 1.1676998740E-1f);
+    p = fma32(p, t, -1.2420140846E-1f);
+    p = fma32(p, t, 1.4249322787E-1f);
+    p = fma32(p, t, -1.6668057665E-1f);
+    p = fma32(p, t, 2.0000714765E-1f);
+    p = fma32(p, t, -2.4999993993E-1f);
+    p = fma32(p, t, 3.3333331174E-1f);
     float y = (t * z) * p;
-    y = y + -0.5f * z;
-    float ln = (t + y) + (float)ex * 0.693147182f;
+    y = fma32(-0.5f, z, y);
+    float ln = fma32((float)ex, 0.693147182f, t + y);
     float r2 = -2.0f * ln;
     if (!(r2 > 0.0f)) r2 = 0.0f;
     float r = sqrt_rn(r2);
@@ -137,13 +140,13 @@ UAV_HD void normal_pair(uint32_t a, uint32_t b, float& z0, float& z1) {
     float phi = (f - 0.5f) * 1.57079637f;
     float zz = phi * phi;
     float s = -1.9515295891E-4f;
-    s = s * zz + 8.3321608736E-3f;
-    s = s * zz + -1.6666654611E-1f;
-    s = (s * zz) * phi + phi;
+    s = fma32(s, zz, 8.3321608736E-3f);
+    s = fma32(s, zz, -1.6666654611E-1f);
+    s = fma32(s * zz, phi, phi);
     float c = 2.443315711809948E-5f;
-    c = c * zz + -1.388731625493765E-3f;
-    c = c * zz + 4.166664568298827E-2f;
-    c = (c * zz) * zz + (1.0f - 0.5f * zz);
+    c = fma32(c, zz, -1.388731625493765E-3f);
+    c = fma32(c, zz, 4.166664568298827E-2f);
+    c = fma32(c * zz, zz, fma32(-0.5f, zz, 1.0f));
     float cs = (q & 1u) ? s : c;
     float sn = (q & 1u) ? c : s;
     if (q == 1u || q == 2u) cs = -cs;

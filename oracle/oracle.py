@@ -10,7 +10,19 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liborc.so")
+def _host_has_fma():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                return " fma " in (line + " ")
+    except OSError:
+        pass
+    return False
+
+
+# same source, same results; the -mfma build inlines the specification's fma() calls (oracle/Makefile)
+LIB_NAME = "liborc.so" if _host_has_fma() else "liborc_nofma.so"
+LIB_PATH = os.path.join(HERE, LIB_NAME)
 MAX_SENSORS = 64
 
 FLAG_RANDOM_LAYOUT, FLAG_FAR_START, FLAG_PROX_SHAPING, FLAG_JAIN_BONUS = 1, 2, 4, 8
@@ -72,7 +84,7 @@ _lib = None
 def build(force=False):
     if force or not os.path.exists(LIB_PATH) or \
             os.path.getmtime(LIB_PATH) < os.path.getmtime(os.path.join(HERE, "uavenv_oracle.c")):
-        subprocess.check_call(["make", "-C", HERE, "-B", "liborc.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", HERE, "-B", "all"], stdout=subprocess.DEVNULL)
 
 
 def lib():

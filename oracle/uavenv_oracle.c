@@ -4,7 +4,8 @@
  * Scalar restatement of the reference UAV-IoT environment hot path.  Every function cites the
  * reference file:line it follows.  Paths are relative to /root/reference/src/.
  *
- * Build: gcc -O2 -ffp-contract=off -fno-fast-math -shared -fPIC  (see oracle/Makefile).
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math [-mfma] -shared -fPIC  (see oracle/Makefile).
+ * The only fused operations are the explicit fma()/fmaf() calls of the noise and log10 specifications.
  * -ffp-contract=off matters: numpy never fuses a*b+c, so neither may we.
  */
 #define _GNU_SOURCE
@@ -101,7 +102,7 @@ static double sf_link_quality(int sf) {
 /* iot_sensors.py:147-189  deterministic part of calculate_rssi (everything before the shadowing
  * draw).  Distances in float32, 20*log10f(d) in float32, the rest in float64. */
 /* log10 of a positive normal float32 in float64, rounded once: the correctly rounded float32 log10
- * except with probability ~1e-8 (absolute error ~1e-15).  A fixed IEEE + - * / sequence (no libm) so
+ * except with probability ~1e-8 (absolute error ~1e-15).  A fixed IEEE + - * / fma sequence (no libm transcendentals) so
  * that the HIP kernel, which evaluates the same specification, agrees bit for bit:
  *   x = m * 2^e, m folded into [sqrt(1/2), sqrt(2));  ln m = 2 atanh(s), s = (m-1)/(m+1), odd series to s^17;
  *   result = e*log10(2) + ln(m)*log10(e).
@@ -116,16 +117,16 @@ float orc_log10_f32(float d) {
     double s = (m - 1.0) / (m + 1.0);
     double s2 = s * s;
     double p = 1.0 / 17;
-    p = p * s2 + 1.0 / 15;
-    p = p * s2 + 1.0 / 13;
-    p = p * s2 + 1.0 / 11;
-    p = p * s2 + 1.0 / 9;
-    p = p * s2 + 1.0 / 7;
-    p = p * s2 + 1.0 / 5;
-    p = p * s2 + 1.0 / 3;
+    p = fma(p, s2, 1.0 / 15);
+    p = fma(p, s2, 1.0 / 13);
+    p = fma(p, s2, 1.0 / 11);
+    p = fma(p, s2, 1.0 / 9);
+    p = fma(p, s2, 1.0 / 7);
+    p = fma(p, s2, 1.0 / 5);
+    p = fma(p, s2, 1.0 / 3);
     double t = 2.0 * s;
-    double ln_m = t + t * (s2 * p);
-    double r = (double)e * 0.30102999566398120 + ln_m * 0.43429448190325182;
+    double ln_m = fma(t, s2 * p, t);
+    double r = fma((double)e, 0.30102999566398120, ln_m * 0.43429448190325182);
     return (float)r;
 }
 
@@ -587,7 +588,7 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 static inline float u32_as_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline uint32_t f32_as_u32(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
-/* Box-Muller on two 32-bit words WITHOUT libm transcendentals: only IEEE float32 +,-,*,sqrt and
+/* Box-Muller on two 32-bit words WITHOUT libm transcendentals: only IEEE float32 +,-,*,fma,sqrt and
  * integer ops, in a fixed order, so CPU and GPU produce bit-identical normals.
  *   radius: u1 = (a>>8 + 1) * 2^-24 in (0,1];  -ln(u1) by exponent split + degree-9 polynomial
  *           (Cephes logf coefficients) on m in [sqrt(1/2), sqrt(2));
@@ -603,17 +604,17 @@ void orc_normal_pair(uint32_t a, uint32_t b, float* z0, float* z1) {
     float t = m - 1.0f;
     float z = t * t;
     float p = 7.0376836292E-2f;
-    p = p * t + -1.1514610310E-1f;
-    p = p * t + 1.1676998740E-1f;
-    p = p * t + -1.2420140846E-1f;
-    p = p * t + 1.4249322787E-1f;
-    p = p * t + -1.6668057665E-1f;
-    p = p * t + 2.0000714765E-1f;
-    p = p * t + -2.4999993993E-1f;
-    p = p * t + 3.3333331174E-1f;
+    p = fmaf(p, t, -1.1514610310E-1f);
+    p = fmaf(p, t, 1.1676998740E-1f);
+    p = fmaf(p, t, -1.2420140846E-1f);
+    p = fmaf(p, t, 1.4249322787E-1f);
+    p = fmaf(p, t, -1.6668057665E-1f);
+    p = fmaf(p, t, 2.0000714765E-1f);
+    p = fmaf(p, t, -2.4999993993E-1f);
+    p = fmaf(p, t, 3.3333331174E-1f);
     float y = (t * z) * p;
-    y = y + -0.5f * z;
-    float ln = (t + y) + (float)ex * 0.693147182f;
+    y = fmaf(-0.5f, z, y);
+    float ln = fmaf((float)ex, 0.693147182f, t + y);
     float r2 = -2.0f * ln;
     if (!(r2 > 0.0f)) r2 = 0.0f;
     float r = sqrtf(r2);
@@ -624,13 +625,13 @@ void orc_normal_pair(uint32_t a, uint32_t b, float* z0, float* z1) {
     float phi = (f - 0.5f) * 1.57079637f;                           /* [-pi/4, pi/4) */
     float zz = phi * phi;
     float s = -1.9515295891E-4f;
-    s = s * zz + 8.3321608736E-3f;
-    s = s * zz + -1.6666654611E-1f;
-    s = (s * zz) * phi + phi;
+    s = fmaf(s, zz, 8.3321608736E-3f);
+    s = fmaf(s, zz, -1.6666654611E-1f);
+    s = fmaf(s * zz, phi, phi);
     float c = 2.443315711809948E-5f;
-    c = c * zz + -1.388731625493765E-3f;
-    c = c * zz + 4.166664568298827E-2f;
-    c = (c * zz) * zz + (1.0f - 0.5f * zz);
+    c = fmaf(c, zz, -1.388731625493765E-3f);
+    c = fmaf(c, zz, 4.166664568298827E-2f);
+    c = fmaf(c * zz, zz, fmaf(-0.5f, zz, 1.0f));
     float cs, sn;
     switch (q) {
         case 0: cs = c; sn = s; break;
