@@ -52,6 +52,7 @@ struct Consts {
     double min_start_dist, prox_eta, jain_weight;
     int32_t max_tries, n_grid_choices;
     int32_t gw[8], gh[8];
+    double inv_small[65];  // RN(1/k), k = 1..64: divisions by a sensor / winner count go through div_const()
 };
 
 // All per-sensor arrays live in ONE allocation, array k at byte offset kOff_k * S where

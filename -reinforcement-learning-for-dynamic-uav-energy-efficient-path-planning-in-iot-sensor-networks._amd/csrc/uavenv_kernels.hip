@@ -113,6 +113,16 @@ template <int G> __device__ __forceinline__ uint32_t gbcast(uint32_t v, int src)
     return gshfl<G>(v, src);
 }
 
+// Sum of `v` over the lanes of `mask` (a group ballot), in ascending lane order.  For the handful of Capture-Effect
+// winners of a collect step this is a few v_readlane + v_add_f64 instead of a full DPP reduction (G = 64: the mask
+// is wave-uniform and the loop runs on the scalar unit; narrower groups use the reduction).
+template <int G> __device__ __forceinline__ double gsum_sparse(double v, uint64_t mask) {
+    if (G != 64) return gsum<G>(v);
+    double acc = 0.0;
+    for (uint64_t m = mask; m != 0ull; m &= m - 1ull) acc += readlane(v, __ffsll((long long)m) - 1);
+    return acc;
+}
+
 // numpy float32 add.reduce order (pairwise sum, n <= 64 < PW_BLOCKSIZE): 8 strided accumulators
 // combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then a sequential tail; plain loop for n < 8.
 // Reproduces np.sum(np.maximum(0, before - after)) at uav_env.py:601 bit for bit.
@@ -493,6 +503,10 @@ __device__ __forceinline__ void draw_step_noise(CRef c, const Ptrs& p, uint32_t 
     normal_pair(w.w0, w.w1, z.zD, z.zE);
     z.u = u24(w.w2);
     z.zA = z.zB = z.zC = 0.f;
+#ifdef UAV_ABL_NOCNOISE      // timing-only ablation build (tools/ablate.py)
+    if (need_collect) { z.zA = z.zE; z.zB = z.zD; z.c2 = w.w2; z.c3 = w.w3; z.zc_ready = false; }
+    need_collect = false;
+#endif
     if (need_collect) {                       // wave-uniform
         Words4 v = noise_words(c.seed, env_index, episode, step, (uint32_t)gl, 1);
         normal_pair(v.w0, v.w1, z.zA, z.zB);
@@ -736,7 +750,11 @@ __device__ __forceinline__ void step_once(CRef c, const Ptrs& p, const StepArgs&
     // post-action position) all share it.
     const double det = rssi_deterministic(c, e.ux, e.uy, s.sx, s.sy);
 
+#ifdef UAV_ABL_NOCOLLECT     // timing-only ablation build
+    const bool any_c = false;
+#else
     const bool any_c = __any(is_c) != 0;
+#endif
     StepNoise z;
     draw_step_noise<G, kLean>(c, p, e.env_index, e.episode, env, in_batch, step, any_c, z);
 
@@ -783,6 +801,9 @@ __device__ __forceinline__ void step_once(CRef c, const Ptrs& p, const StepArgs&
         int others = 0;
         double omax = -__builtin_inf();
         bool lower_same = false, beaten = false;
+#ifdef UAV_ABL_NOCAPTURE      // timing-only ablation build
+        m = 0ull;
+#endif
         while (__any(m != 0ull)) {
             int j = m ? (__ffsll((long long)m) - 1) : 0;
             double cj = gbcast<G>(cur, j);
@@ -813,10 +834,11 @@ __device__ __forceinline__ void step_once(CRef c, const Ptrs& p, const StepArgs&
             got = take & (by > 0);
             s.flags |= got ? kDataCollected : 0u;
         }
-        const double total_bytes = gsum<G>(bytes);
+        const uint64_t winner_mask = gballot<G>(winner);
+        const double total_bytes = gsum_sparse<G>(bytes, winner_mask);          // bytes is 0 off the winners
         const bool any_new = gany<G>(got & !(s.flags & kVisited));
         s.flags |= got ? kVisited : 0u;
-        const int nw = __popcll(gballot<G>(winner));
+        const int nw = __popcll(winner_mask);
         const bool attempted_empty = gany<G>(actc & (s.b <= 0));                // :596
         const bool all_collected = !gany<G>(actc & (s.b > 0));                  // :604
         // P5 :599-602 (float32); only drained sensors changed their AoI urgency
@@ -831,20 +853,26 @@ __device__ __forceinline__ void step_once(CRef c, const Ptrs& p, const StepArgs&
         double mean_urgency = 0.0;
         if (__any(winner)) {
             const double ui = winner ? calc_urgency(c, s.b, s.gen, s.lost) : 0.0;
-            const double su = gsum<G>(ui);
-            mean_urgency = nw > 0 ? su / nw : 0.0;
+            const double su = gsum_sparse<G>(ui, winner_mask);
+            mean_urgency = nw > 0 ? div_const(su, (double)nw, c.inv_small[nw]) : 0.0;
         }
         // reward_function.py:46-57 variance "starvation" penalty (np.var: two-pass, ddof 0)
         double starvation = 0.0;
+#ifndef UAV_ABL_NOVAR           // timing-only ablation build
         {
-            const double mx = gmax<G>(actc ? s.b : -__builtin_inf());
+            // a buffer never exceeds its cap, so the maximum is the cap itself as soon as one sensor is full
+            // (the steady state); only otherwise is the max-reduction needed
+            double mx = c.bmax;
+            if (G != 64 || !gany<G>(actc & (s.b == c.bmax))) mx = gmax<G>(actc ? s.b : -__builtin_inf());   // wave-uniform branch
             const bool use = (n > 1) & (mx != 0);
             const double nb = (actc & use) ? s.b / mx : 0.0;
-            const double mean = gsum<G>(nb) / n;
+            const double inv_n = c.inv_small[n];
+            const double mean = div_const(gsum<G>(nb), (double)n, inv_n);
             const double dv = (actc & use) ? (nb - mean) * (nb - mean) : 0.0;
-            const double var = gsum<G>(dv) / n;
+            const double var = div_const(gsum<G>(dv), (double)n, inv_n);
             starvation = use ? c.p_starvation * var : 0.0;
         }
+#endif
         {
             double rw = c.p_step + c.p_hover;                                   // reward_function.py:97
             {
