@@ -9,12 +9,15 @@
 namespace uavenv {
 
 #ifndef UAV_BLOCK
-#define UAV_BLOCK 256
+#define UAV_BLOCK 1024
 #endif
 #ifndef UAV_LDS_PAD       // dev-only occupancy cap for launch-shape experiments (tools/ablate.py)
 #define UAV_LDS_PAD 0
 #endif
-constexpr int kBlockThreads = UAV_BLOCK;    // 4 wavefronts per workgroup
+// 16 wavefronts per workgroup = one workgroup per CU at the headline size, wavefront w on SIMD (w + const) mod 4
+// (tools/wave_map.py): the step kernel deals the expensive collect-action environments of a workgroup round-robin over
+// the four SIMDs (StepArgs::balance).
+constexpr int kBlockThreads = UAV_BLOCK;
 
 // flag word per sensor (UAVENV_F_FLAGS)
 constexpr uint32_t kSfMask = 15u, kAvgValid = 16u, kVisited = 32u, kDataCollected = 64u;
@@ -89,6 +92,14 @@ struct StepArgs {
     int32_t policy;             // UAVENV_POLICY_*
     float* aux;                 // optional float [E][4] = (action, reward, done, terminal-pool row or -1): the packed
                                 // remainder of a transition block, so that replay insertion needs no pack kernel
+    // SIMD load balancing (a pure scheduling hint: any value gives the same results).  balance != 0: the wavefronts of
+    // a workgroup take its environments collect-actions-first, so collect steps (1.6x the work of a move) spread evenly
+    // over the CU's SIMDs.  The "is a collect" bits come from `actions`, or for the in-kernel random policy from
+    // hint_in[wave unit] -- written by the PREVIOUS launch into its hint_out (double-buffered by the host: a launch never
+    // writes the buffer its own wavefronts read).
+    const uint8_t* hint_in;
+    uint8_t* hint_out;
+    int32_t balance;
 };
 
 struct ResetArgs {

@@ -687,6 +687,13 @@ __device__ __forceinline__ void step_once(CRef c, const Ptrs& p, const StepArgs&
         Words4 w = noise_words(c.seed, e.env_index, e.episode, step, 0u, 3);
         action = (int)(((uint64_t)w.w0 * 5u) >> 32);
         if (a.actions_out != nullptr && in_batch && gl == 0) a.actions_out[env] = action;
+        // Scheduling hint for the NEXT launch (StepArgs::balance): will the following random action be a collect?
+        // Same draw one step ahead, on the scalar unit while the state loads are in flight (G = 64 only).  An
+        // episode that ends in this step makes the hint wrong, which costs balance for one launch, nothing else.
+        if (!kRegs && G == 64 && a.hint_out != nullptr) {
+            const Words4 w2 = noise_words(c.seed, e.env_index, e.episode, step + 1u, 0u, 3);
+            if (gl == 0) a.hint_out[env] = ((((uint64_t)w2.w0 * 5u) >> 32) == 4u) ? 1 : 0;
+        }
     }
     const bool is_c = action == 4;
     const bool is_m = (action >= 0) & (action <= 3);
@@ -1022,7 +1029,40 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_ker
     const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const int gl = group_lane<G>();
-    const uint32_t env = blockIdx.x * (kBlockThreads / G) + uni<G>((int)(threadIdx.x / G));
+    // ---- which environments does this wavefront step?  Home mapping: wave w takes unit w (= 64/G consecutive
+    // environments).  Balanced mapping: units holding a collect action first, so that the collect steps of this
+    // workgroup are dealt round-robin over the SIMDs (waves w, w+4, w+8, w+12 share one).
+    constexpr int kWaves = kBlockThreads / 64, kEnvsPerWave = 64 / G;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int unit = wave;
+    if (kWaves >= 4 && a.balance != 0) {                             // kernel-uniform
+        // one bit per unit of this workgroup, fetched with scalar loads (wave-uniform addresses, memory no
+        // wavefront of this launch writes) and assembled on the scalar unit
+        typedef const __attribute__((address_space(4))) uint32_t* CU32;
+        uint32_t mask = 0u;
+        if (a.actions != nullptr) {
+            CU32 ap = (CU32)(a.actions) + (size_t)blockIdx.x * (kWaves * kEnvsPerWave);
+            const int left = a.num_envs - (int)(blockIdx.x * (kWaves * kEnvsPerWave));     // envs of this block in the batch
+#pragma unroll
+            for (int t = 0; t < kWaves * kEnvsPerWave; t++) {
+                const uint32_t av = t < left ? ap[t] : 0u;         // padding environments have no action
+                mask |= (av == 4u ? 1u : 0u) << (t / kEnvsPerWave);
+            }
+        } else {
+            CU32 hp = (CU32)(a.hint_in + (size_t)blockIdx.x * kWaves);
+#pragma unroll
+            for (int q = 0; q < kWaves / 4; q++) {
+                const uint32_t w = hp[q];                          // four 0/1 bytes
+                mask |= ((w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u)) << (4 * q);
+            }
+        }
+        const uint32_t full = kWaves >= 32 ? 0xFFFFFFFFu : ((1u << (kWaves & 31)) - 1u);
+        const int nc = __popc(mask);
+        uint32_t m = wave < nc ? mask : (~mask & full);
+        for (int k = wave < nc ? wave : wave - nc; k > 0; k--) m &= m - 1u;       // scalar: drop the k lowest candidates
+        unit = __ffs((int)m) - 1;
+    }
+    const uint32_t env = (blockIdx.x * kWaves + (uint32_t)unit) * kEnvsPerWave + uni<G>((int)((threadIdx.x & 63u) / G));
     const uint32_t idx = env * G + gl;
     const bool in_batch = env < (uint32_t)a.num_envs;
     Sensor s;
