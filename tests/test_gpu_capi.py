@@ -83,3 +83,39 @@ def test_many_handles_create_destroy():
         e = U.BatchedUAVEnv(2048, num_sensors=50); e.reset(); e.step_random(); e.close()
     torch.cuda.synchronize()
     assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)      # no leak beyond allocator slack
+
+
+_BALANCE_CHILD = r'''
+import sys, hashlib
+sys.path.insert(0, %r)
+import torch, uavenv_amd as U
+h = hashlib.sha256()
+for E, n in ((37, 50), (256, 50), (100, 20), (64, 10)):
+    env = U.BatchedUAVEnv(E, num_sensors=n, seed=5, max_steps=30)
+    env.reset()
+    g = torch.Generator(device="cpu"); g.manual_seed(E)
+    for s in range(70):
+        if s %% 3 == 2:
+            env.step_random()
+        else:
+            a = torch.randint(0, 5, (E,), generator=g, dtype=torch.int32).to(env.device)
+            env.step(a)
+        h.update(env.obs.cpu().numpy().tobytes()); h.update(env.reward.cpu().numpy().tobytes()); h.update(env.done.cpu().numpy().tobytes())
+    sd = env.state_dict()
+    for k in sorted(sd):
+        h.update(sd[k].cpu().numpy().tobytes())
+    env.close()
+print("DIGEST", h.hexdigest())
+'''
+
+
+def test_simd_load_balancing_is_a_pure_scheduling_choice():
+    """The step kernel hands the environments of a workgroup to its wavefronts collect-actions-first (StepArgs::balance).
+    Which wavefront steps which environment must not change a single bit: same digest with the home mapping."""
+    import sys
+    outs = []
+    for flag in ("0", "1"):
+        out = subprocess.check_output([sys.executable, "-c", _BALANCE_CHILD % ROOT], text=True,
+                                      env=dict(os.environ, UAVENV_NO_BALANCE=flag))
+        outs.append([l for l in out.splitlines() if l.startswith("DIGEST")][0])
+    assert outs[0] == outs[1]
