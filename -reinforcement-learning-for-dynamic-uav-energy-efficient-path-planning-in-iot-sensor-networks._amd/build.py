@@ -13,7 +13,9 @@ LIB = os.path.join(HERE, "libuavenv_hip.so")
 SOURCES = ["uavenv_kernels.hip", "uavenv_capi.hip", "uavenv_attention.hip"]
 HEADERS = ["uavenv_internal.h", "uavenv_noise.h", os.path.join("..", "..", "include", "uavenv.h")]
 # -ffp-contract=off: the float64 state has to follow the reference's (numpy, unfused) operation order.
-FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall", "-Wno-bitwise-instead-of-logical"]
+# kernarg preload: the leading scalar kernel arguments arrive in SGPRs with the wave launch (see uav_step_kernel).
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall", "-Wno-bitwise-instead-of-logical",
+         "-mllvm", "-amdgpu-kernarg-preload-count=7"]
 
 
 def hipcc():

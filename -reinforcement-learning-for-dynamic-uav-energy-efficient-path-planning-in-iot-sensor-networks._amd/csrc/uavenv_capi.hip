@@ -31,7 +31,7 @@ struct UavEnv {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float* term_pool = nullptr; uint32_t* term_counter = nullptr; int32_t* term_index = nullptr; int32_t term_rows = 0;
     float* aux_out = nullptr;
-    uint8_t* hints = nullptr;       // [2][padded_envs] scheduling hints of the random-policy step (StepArgs::balance)
+    uint32_t* hints = nullptr;      // [2][padded_envs] scheduling hints of the random-policy step (StepArgs::balance)
     int hint_parity = 0;
     bool balance = true;            // UAVENV_NO_BALANCE=1 in the environment keeps the home mapping (A/B timing)
     std::string err;
@@ -204,7 +204,7 @@ extern "C" int uavenv_create(const UavEnvConfig* cfg, int32_t num_envs, uint32_t
     size_t o_s = off; off += al(P * sizeof(UavEnvEpisodeStats));
     size_t o_st = off; off += 256;
     size_t o_c = off; off += al(sizeof(Consts));
-    size_t o_h = off; off += al(2 * P);
+    size_t o_h = off; off += al(2 * P * sizeof(uint32_t));
     e->block_bytes = off;
     st = hipMalloc(&e->block, off);
     if (st != hipSuccess) return bail(UAVENV_E_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(st));
@@ -213,7 +213,7 @@ extern "C" int uavenv_create(const UavEnvConfig* cfg, int32_t num_envs, uint32_t
     e->ptrs.rec = (UavEnvRecord*)(base + o_r); e->ptrs.stats = (UavEnvEpisodeStats*)(base + o_s);
     e->ptrs.status = (uint32_t*)(base + o_st);
     e->dev_consts = (Consts*)(base + o_c);
-    e->hints = (uint8_t*)(base + o_h);
+    e->hints = (uint32_t*)(base + o_h);
     { const char* nb = getenv("UAVENV_NO_BALANCE"); e->balance = !(nb && nb[0] == '1'); }
     e->ptrs.step_tape = nullptr; e->ptrs.reset_tape = nullptr; e->ptrs.stamps = nullptr;
     st = hipMemset(e->block, 0, off);
@@ -321,14 +321,12 @@ static int step_common(UavEnv* e, int32_t policy, const int32_t* actions, int32_
     if (policy == UAVENV_POLICY_ACTIONS && !actions) return fail(e, UAVENV_E_INVALID, "actions_dev is NULL");
     StepArgs a{actions, actions_out, obs, rew, rew32, done, term, e->num_envs,
                e->term_pool, e->term_counter, e->term_index, e->term_rows, policy, e->aux_out, nullptr, nullptr, 0};
-    if (!e->balance) {}
-    else if (policy == UAVENV_POLICY_ACTIONS) a.balance = 1;
-    else if (policy == UAVENV_POLICY_RANDOM && e->G == 64 && e->hints != nullptr) {
-        a.hint_in = e->hints + (size_t)e->hint_parity * (size_t)e->padded_envs;
+    a.hint_in = e->hints + (size_t)e->hint_parity * (size_t)e->padded_envs;          // always a readable buffer
+    a.balance = e->balance ? 1 : 0;
+    if (policy == UAVENV_POLICY_RANDOM && e->G == 64) {           // this launch leaves the next launch's hints
         a.hint_out = e->hints + (size_t)(e->hint_parity ^ 1) * (size_t)e->padded_envs;
-        a.balance = 1;
         e->hint_parity ^= 1;
-    }
+    } else if (policy != UAVENV_POLICY_ACTIONS) a.balance = 0;   // no cheap way to know the actions up front
     HIP_TRY(e, launch_step(e->G, e->padded_envs, e->consts, e->dev_consts, e->ptrs, a, (hipStream_t)stream));
     return UAVENV_OK;
 }

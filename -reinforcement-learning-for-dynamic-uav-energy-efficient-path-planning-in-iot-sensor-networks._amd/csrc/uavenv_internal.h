@@ -97,8 +97,8 @@ struct StepArgs {
     // over the CU's SIMDs.  The "is a collect" bits come from `actions`, or for the in-kernel random policy from
     // hint_in[wave unit] -- written by the PREVIOUS launch into its hint_out (double-buffered by the host: a launch never
     // writes the buffer its own wavefronts read).
-    const uint8_t* hint_in;
-    uint8_t* hint_out;
+    const uint32_t* hint_in;    // never null (one word per padded environment)
+    uint32_t* hint_out;         // null unless the random policy writes next-step hints
     int32_t balance;
 };
 

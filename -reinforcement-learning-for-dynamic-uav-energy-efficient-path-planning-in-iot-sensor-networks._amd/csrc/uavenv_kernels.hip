@@ -27,6 +27,15 @@
 
 namespace uavenv {
 
+#ifdef UAVENV_STAMPS
+// diagnostic build: phase timestamps of the step, 16 words per environment, stored behind the per-wave records
+// (p.stamps + kPhaseBase); tools/phases.py reads them.
+#define UAV_PHASE(i) do { if (!kRegs && p.stamps != nullptr && gl == 0) p.stamps[(1u << 20) + (size_t)env * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define UAV_PHASE(i) do {} while (0)
+#endif
+
+
 // The constants live in device memory and are read through the CONSTANT address space: scalar loads
 // (s_load) issued where a field is used.  (Passing the 600-byte struct by value makes the compiler load
 // every field in the entry block and then spill ~80 SGPRs to VGPR lanes.)
@@ -317,17 +326,20 @@ struct Sensor {
 };
 
 // SoA arrays inside the single state allocation (uavenv_internal.h): array base = sensor_base + off * S.
-template <typename T> __device__ __forceinline__ T* sensor_array(const Ptrs& p, uint64_t off) {
+struct SensorBase { char* sensor_base; uint64_t lanes; };      // the two fields sensor_array() needs, e.g. from preloaded SGPRs
+// (`P` / `A` template parameters below: Ptrs / StepArgs either as a private copy or, in the step kernel, read in
+// place from the kernarg segment through the constant address space -- fields are then fetched where they are used.)
+template <typename T, typename P> __device__ __forceinline__ T* sensor_array(const P& p, uint64_t off) {
     return reinterpret_cast<T*>(p.sensor_base + off * p.lanes);
 }
-template <int G> __device__ __forceinline__ void load_sensor(const Ptrs& p, uint32_t idx, Sensor& s) {
+template <int G, typename P> __device__ __forceinline__ void load_sensor(const P& p, uint32_t idx, Sensor& s) {
     s.sx = sensor_array<float>(p, kOffPosX)[idx]; s.sy = sensor_array<float>(p, kOffPosY)[idx];
     s.b = sensor_array<double>(p, kOffBuffer)[idx]; s.gen = sensor_array<double>(p, kOffGen)[idx];
     s.tx = sensor_array<double>(p, kOffTx)[idx]; s.lost = sensor_array<double>(p, kOffLost)[idx];
     s.avg = sensor_array<double>(p, kOffAvg)[idx];
     s.flags = sensor_array<uint32_t>(p, kOffFlags)[idx];
 }
-template <int G> __device__ __forceinline__ void store_sensor(const Ptrs& p, uint32_t idx, const Sensor& s, bool with_pos) {
+template <int G, typename P> __device__ __forceinline__ void store_sensor(const P& p, uint32_t idx, const Sensor& s, bool with_pos) {
     if (with_pos) { sensor_array<float>(p, kOffPosX)[idx] = s.sx; sensor_array<float>(p, kOffPosY)[idx] = s.sy; }
     sensor_array<double>(p, kOffBuffer)[idx] = s.b; sensor_array<double>(p, kOffGen)[idx] = s.gen;
     sensor_array<double>(p, kOffTx)[idx] = s.tx; sensor_array<double>(p, kOffLost)[idx] = s.lost;
@@ -415,8 +427,8 @@ __device__ __forceinline__ void observe(CRef c, Sensor& s, int n, int gw, int gh
 struct StepNoise { float zA, zB, u, zC, zD, zE; uint32_t c2, c3; bool zc_ready; };
 
 // zP: the shadowing sample of the is_in_range() call a heuristic policy makes before the step (Philox call 5)
-template <int G, bool kLean>
-__device__ __forceinline__ float draw_policy_noise(CRef c, const Ptrs& p, uint32_t env_index, uint32_t episode, size_t env,
+template <int G, bool kLean, typename P>
+__device__ __forceinline__ float draw_policy_noise(CRef c, const P& p, uint32_t env_index, uint32_t episode, size_t env,
                                                    bool in_batch, uint32_t step) {
     const int gl = group_lane<G>();
     if (UAV_TAPE(p.step_tape) != nullptr)
@@ -485,8 +497,8 @@ __device__ __forceinline__ int policy_action(CRef c, const Sensor& s, const Env&
     return (collect | (pick == 0ull)) ? 4 : mv;
 }
 
-template <int G, bool kLean>
-__device__ __forceinline__ void draw_step_noise(CRef c, const Ptrs& p, uint32_t env_index, uint32_t episode,
+template <int G, bool kLean, typename P>
+__device__ __forceinline__ void draw_step_noise(CRef c, const P& p, uint32_t env_index, uint32_t episode,
                                                 size_t env, bool in_batch, uint32_t step, bool need_collect, StepNoise& z) {
     const int gl = group_lane<G>();
     z.c2 = z.c3 = 0u; z.zc_ready = true;
@@ -520,8 +532,8 @@ __device__ __forceinline__ void finish_zc(StepNoise& z) {   // call under wave-u
 // uav_env.py:400-427 reset (+ iot_sensors.py:305-321, uav.py:241-258; DomainRandEnv.reset
 // dqn.py:301-373 under the flags) for the groups with `rs` set.  Leaves the new episode's sensor
 // registers in `s`, the record in `r`, and returns (zD, zE) of the reset observation.
-template <int G, bool kLean>
-__device__ __forceinline__ void reset_group(CRef c, const Ptrs& p, Sensor& s, UavEnvRecord& r, size_t env,
+template <int G, bool kLean, typename P>
+__device__ __forceinline__ void reset_group(CRef c, const P& p, Sensor& s, UavEnvRecord& r, size_t env,
                                             bool in_batch, bool rs, bool draw_layout, float& zD, float& zE) {
     const int gl = group_lane<G>();
     if (!rs) return;                                   // group-uniform; no cross-lane ops skipped below
@@ -666,11 +678,12 @@ __global__ __launch_bounds__(kBlockThreads) void uav_reset_kernel(const Consts* 
 // global memory) and the fused rollout kernel (record staged in LDS, sensor state kept in registers
 // across steps).  `rec` may point to global memory or LDS.
 // ---------------------------------------------------------------------------------------------
-template <int G, bool kLean, bool kRegs = false, typename RecPtr = UavEnvRecord*>
-__device__ __forceinline__ void step_once(CRef c, const Ptrs& p, const StepArgs& a, uint32_t env, bool in_batch,
+template <int G, bool kLean, bool kRegs = false, typename RecPtr = UavEnvRecord*, typename P = Ptrs, typename A = StepArgs>
+__device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32_t env, bool in_batch,
                                           RecPtr rec, Sensor& s, bool& wrote_pos, uint32_t& status_or,
                                           int& action_out) {
     const int gl = group_lane<G>();
+    UAV_PHASE(0);
     Env e = load_env<G>(rec);
     const int n = e.n;
     const bool act = gl < n;
@@ -684,20 +697,29 @@ __device__ __forceinline__ void step_once(CRef c, const Ptrs& p, const StepArgs&
         if (a.actions_out != nullptr && in_batch && gl == 0) a.actions_out[env] = action;
     } else if (UAV_POLICY(a) == UAVENV_POLICY_ACTIONS) action = uni<G>(in_batch ? a.actions[env] : 0);
     else {                                                       // uniform-random policy (Philox call 3)
+#ifdef UAV_ABL_CHEAPACTION   // timing-only ablation build: no Philox on the scalar unit for the action / the hint
+        action = (int)((e.env_index * 7u + step * 3u + e.episode) % 5u);
+#else
         Words4 w = noise_words(c.seed, e.env_index, e.episode, step, 0u, 3);
         action = (int)(((uint64_t)w.w0 * 5u) >> 32);
+#endif
         if (a.actions_out != nullptr && in_batch && gl == 0) a.actions_out[env] = action;
         // Scheduling hint for the NEXT launch (StepArgs::balance): will the following random action be a collect?
         // Same draw one step ahead, on the scalar unit while the state loads are in flight (G = 64 only).  An
         // episode that ends in this step makes the hint wrong, which costs balance for one launch, nothing else.
         if (!kRegs && G == 64 && a.hint_out != nullptr) {
+#ifdef UAV_ABL_CHEAPACTION
+            if (gl == 0) a.hint_out[env] = ((e.env_index * 7u + (step + 1u) * 3u + e.episode) % 5u) == 4u ? 4u : 0u;
+#else
             const Words4 w2 = noise_words(c.seed, e.env_index, e.episode, step + 1u, 0u, 3);
-            if (gl == 0) a.hint_out[env] = ((((uint64_t)w2.w0 * 5u) >> 32) == 4u) ? 1 : 0;
+            if (gl == 0) a.hint_out[env] = (uint32_t)(((uint64_t)w2.w0 * 5u) >> 32);       // the action itself: 4 = collect
+#endif
         }
     }
     const bool is_c = action == 4;
     const bool is_m = (action >= 0) & (action <= 3);
     const uint32_t status_bits = (!is_c & !is_m) ? 1u : 0u;     // uav_env.py:468 ValueError (after ageing)
+    UAV_PHASE(1);
 
     // ---- uav_env.py:439-447: step counter, edge-cell bookkeeping on the PRE-move position --------
     e.step += 1;
@@ -722,6 +744,7 @@ __device__ __forceinline__ void step_once(CRef c, const Ptrs& p, const StepArgs&
         loss = act ? l : 0.0;
     }
     const double step_data_loss = gsum<G>(loss);
+    UAV_PHASE(2);
 
     double reward = 0.0;
     double bytes_step = 0.0;          // uav_env.py:607 last_step_bytes_collected
@@ -756,6 +779,7 @@ __device__ __forceinline__ void step_once(CRef c, const Ptrs& p, const StepArgs&
     // UAV, so the five RSSI samples of a step (zA,zB,zC at the pre-action position, zD,zE at the
     // post-action position) all share it.
     const double det = rssi_deterministic(c, e.ux, e.uy, s.sx, s.sy);
+    UAV_PHASE(3);
 
 #ifdef UAV_ABL_NOCOLLECT     // timing-only ablation build
     const bool any_c = false;
@@ -764,6 +788,7 @@ __device__ __forceinline__ void step_once(CRef c, const Ptrs& p, const StepArgs&
 #endif
     StepNoise z;
     draw_step_noise<G, kLean>(c, p, e.env_index, e.episode, env, in_batch, step, any_c, z);
+    UAV_PHASE(4);
 
     // ---- :518-632 collect with Capture-Effect collision handling ---------------------------------
     if (any_c) {
@@ -914,6 +939,7 @@ __device__ __forceinline__ void step_once(CRef c, const Ptrs& p, const StepArgs&
         reward = truncated ? rt : reward;
     }
     const double reward_unshaped = reward;                                        // :487 total_reward += reward
+    UAV_PHASE(5);
 
     // ---- observation of the stepped state (side effect: ADR EMA) -------------------------------
     const bool auto_reset = (UAV_FLAGS(c) & UAVENV_FLAG_AUTO_RESET) != 0;
@@ -942,6 +968,7 @@ __device__ __forceinline__ void step_once(CRef c, const Ptrs& p, const StepArgs&
     // ---- epilogue: the cold part of the record (read late on purpose: see struct Env) -----------------
     asm volatile("" ::: "memory");
     UavEnvRecord r = *rec;
+    UAV_PHASE(6);
     if (G == 64) {      // wave-uniform: keep the record in SGPRs (matters when `rec` is LDS: ds_read lands in VGPRs)
         union { UavEnvRecord r; int w[32]; } u;
         u.r = r;
@@ -1015,6 +1042,7 @@ __device__ __forceinline__ void step_once(CRef c, const Ptrs& p, const StepArgs&
     }
     if (kRegs) *rec = r; else if (gl == 0) *rec = r;
     status_or |= r.status;
+    UAV_PHASE(7);
 
     action_out = action;
 }
@@ -1023,7 +1051,23 @@ __device__ __forceinline__ void step_once(CRef c, const Ptrs& p, const StepArgs&
 // step kernel: one launch = one step() of every environment
 // ---------------------------------------------------------------------------------------------
 template <int G, bool kLean>
-__global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_kernel(const Consts* cptr, Ptrs p, StepArgs a) {
+__global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_kernel(
+        // The first seven arguments repeat fields of the two structs: they are the pointers the first loads of a wave
+        // need, and as leading scalar arguments they arrive PRELOADED in SGPRs with the wave launch (gfx950 kernarg
+        // preload, -mllvm -amdgpu-kernarg-preload-count=7 in build.py) instead of behind a kernarg-segment round trip.
+        const Consts* cptr, char* sensor_base, uint64_t lanes, UavEnvRecord* rec_base, const uint32_t* hint_in,
+        const int32_t* actions, uint64_t balance_and_envs, Ptrs p_in, StepArgs a_in) {
+    // The two structs are NOT taken from the parameters (that would load every field at the kernel entry and spill
+    // them): they are read in place from the kernarg segment, field by field where used, like the constants block.
+    struct Kernargs { const Consts* cptr; char* sensor_base; uint64_t lanes; UavEnvRecord* rec; const uint32_t* hint_in;
+                      const int32_t* actions; uint64_t be; Ptrs p; StepArgs a; };
+    typedef const __attribute__((address_space(4))) unsigned char* KA;
+    KA ka = (KA)__builtin_amdgcn_kernarg_segment_ptr();
+    const __attribute__((address_space(4))) Ptrs& p = *(const __attribute__((address_space(4))) Ptrs*)(ka + offsetof(Kernargs, p));
+    const __attribute__((address_space(4))) StepArgs& a = *(const __attribute__((address_space(4))) StepArgs*)(ka + offsetof(Kernargs, a));
+    const SensorBase sb{sensor_base, lanes};
+    const int32_t num_envs = (int32_t)(uint32_t)balance_and_envs;
+    const bool balance = (balance_and_envs >> 32) != 0ull;
     UAV_CONSTS(cptr);
 #ifdef UAVENV_STAMPS
     const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
@@ -1035,43 +1079,37 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_ker
     constexpr int kWaves = kBlockThreads / 64, kEnvsPerWave = 64 / G;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int unit = wave;
-    if (kWaves >= 4 && a.balance != 0) {                             // kernel-uniform
-        // one bit per unit of this workgroup, fetched with scalar loads (wave-uniform addresses, memory no
-        // wavefront of this launch writes) and assembled on the scalar unit
+    if (kWaves >= 4) {
+        // One word per environment of this workgroup, "== 4" meaning "steps a collect action": the caller's action
+        // array, or for the in-kernel random policy the words the PREVIOUS launch left in hint_in (one step ahead draw).
+        // Fetched with ONE scalar load whose address needs only preloaded arguments and the workgroup id, so it is
+        // issued with the first instructions of the wave (the last, partial workgroup of an action array reads the
+        // hint words instead of running past the array's end: any bits give a valid schedule).
         typedef const __attribute__((address_space(4))) uint32_t* CU32;
+        constexpr int kWords = kWaves * kEnvsPerWave;
+        const bool from_actions = (actions != nullptr) & ((int)(blockIdx.x * kWords) + kWords <= (int)(uint32_t)balance_and_envs);
+        CU32 src = (from_actions ? (CU32)actions : (CU32)hint_in) + (size_t)blockIdx.x * kWords;
         uint32_t mask = 0u;
-        if (a.actions != nullptr) {
-            CU32 ap = (CU32)(a.actions) + (size_t)blockIdx.x * (kWaves * kEnvsPerWave);
-            const int left = a.num_envs - (int)(blockIdx.x * (kWaves * kEnvsPerWave));     // envs of this block in the batch
 #pragma unroll
-            for (int t = 0; t < kWaves * kEnvsPerWave; t++) {
-                const uint32_t av = t < left ? ap[t] : 0u;         // padding environments have no action
-                mask |= (av == 4u ? 1u : 0u) << (t / kEnvsPerWave);
-            }
-        } else {
-            CU32 hp = (CU32)(a.hint_in + (size_t)blockIdx.x * kWaves);
-#pragma unroll
-            for (int q = 0; q < kWaves / 4; q++) {
-                const uint32_t w = hp[q];                          // four 0/1 bytes
-                mask |= ((w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u)) << (4 * q);
-            }
+        for (int t = 0; t < kWords; t++) mask |= (src[t] == 4u ? 1u : 0u) << (t / kEnvsPerWave);
+        if (balance) {                                               // kernel-uniform
+            const uint32_t full = kWaves >= 32 ? 0xFFFFFFFFu : ((1u << (kWaves & 31)) - 1u);
+            const int nc = __popc(mask);
+            uint32_t m = wave < nc ? mask : (~mask & full);
+            for (int k = wave < nc ? wave : wave - nc; k > 0; k--) m &= m - 1u;   // scalar: drop the k lowest candidates
+            unit = __ffs((int)m) - 1;
         }
-        const uint32_t full = kWaves >= 32 ? 0xFFFFFFFFu : ((1u << (kWaves & 31)) - 1u);
-        const int nc = __popc(mask);
-        uint32_t m = wave < nc ? mask : (~mask & full);
-        for (int k = wave < nc ? wave : wave - nc; k > 0; k--) m &= m - 1u;       // scalar: drop the k lowest candidates
-        unit = __ffs((int)m) - 1;
     }
     const uint32_t env = (blockIdx.x * kWaves + (uint32_t)unit) * kEnvsPerWave + uni<G>((int)((threadIdx.x & 63u) / G));
     const uint32_t idx = env * G + gl;
-    const bool in_batch = env < (uint32_t)a.num_envs;
+    const bool in_batch = env < (uint32_t)num_envs;
     Sensor s;
-    load_sensor<G>(p, idx, s);
+    load_sensor<G>(sb, idx, s);
     bool wrote_pos = false;
     uint32_t status_or = 0u;
     int action = 0;
-    step_once<G, kLean>(c, p, a, env, in_batch, p.rec + env, s, wrote_pos, status_or, action);
-    store_sensor<G>(p, idx, s, wrote_pos);
+    step_once<G, kLean>(c, p, a, env, in_batch, rec_base + env, s, wrote_pos, status_or, action);
+    store_sensor<G>(sb, idx, s, wrote_pos);
     if (gl == 0 && status_or) atomicOr(p.status, status_or);
 #ifdef UAVENV_STAMPS
     if (p.stamps != nullptr && (threadIdx.x & 63u) == 0) {
@@ -1249,8 +1287,9 @@ hipError_t launch_reset(int Gw, int padded_envs, const Consts& c, const Consts* 
 }
 hipError_t launch_step(int Gw, int padded_envs, const Consts& c, const Consts* dc, const Ptrs& p, const StepArgs& a, hipStream_t s) {
     dim3 block(kBlockThreads), grid((unsigned)(padded_envs / (kBlockThreads / Gw)));
-    if (lean_ok(c, p, a)) { UAV_DISPATCH_G(Gw, (uav_step_kernel<G, true><<<grid, block, lds_bytes(Gw, c), s>>>(dc, p, a))); }
-    else { UAV_DISPATCH_G(Gw, (uav_step_kernel<G, false><<<grid, block, lds_bytes(Gw, c), s>>>(dc, p, a))); }
+    const uint64_t be = ((uint64_t)(uint32_t)a.balance << 32) | (uint64_t)(uint32_t)a.num_envs;
+    if (lean_ok(c, p, a)) { UAV_DISPATCH_G(Gw, (uav_step_kernel<G, true><<<grid, block, lds_bytes(Gw, c), s>>>(dc, p.sensor_base, p.lanes, p.rec, a.hint_in, a.actions, be, p, a))); }
+    else { UAV_DISPATCH_G(Gw, (uav_step_kernel<G, false><<<grid, block, lds_bytes(Gw, c), s>>>(dc, p.sensor_base, p.lanes, p.rec, a.hint_in, a.actions, be, p, a))); }
     return hipGetLastError();
 }
 hipError_t launch_rollout(int Gw, int padded_envs, const Consts& c, const Consts* dc, const Ptrs& p, const StepArgs& a,

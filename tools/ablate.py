@@ -8,6 +8,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PKG = os.path.join(ROOT, "-reinforcement-learning-for-dynamic-uav-energy-efficient-path-planning-in-iot-sensor-networks._amd")
+sys.path.insert(0, PKG)
+import build as _build  # noqa: E402  (the package's build.py: one place for the compiler flags)
+HIPCC_FLAGS = [f for f in _build.FLAGS if f != "-Wall"]
 OUT = os.path.join(ROOT, "gpurun_out", "ablate")
 os.makedirs(OUT, exist_ok=True)
 VARIANTS = [("base", []), ("no_log10", ["-DUAV_ABL_LOG10"]), ("philox6", ["-DUAV_ABL_PHILOX=6"]), ("no_normal", ["-DUAV_ABL_NORMAL"])]
@@ -16,7 +19,7 @@ procs = []
 for name, flags in VARIANTS:
     lib = os.path.join(OUT, f"lib_{name}.so")
     procs.append((name, lib, subprocess.Popen(
-        ["hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"] + flags +
+        ["hipcc"] + HIPCC_FLAGS + flags +
         ["-o", lib, os.path.join(PKG, "csrc", "uavenv_kernels.hip"), os.path.join(PKG, "csrc", "uavenv_capi.hip"), os.path.join(PKG, "csrc", "uavenv_attention.hip")])))
 for name, lib, p in procs:
     assert p.wait() == 0, name

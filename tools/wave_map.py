@@ -10,10 +10,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PKG = os.path.join(ROOT, "-reinforcement-learning-for-dynamic-uav-energy-efficient-path-planning-in-iot-sensor-networks._amd")
+sys.path.insert(0, PKG)
+import build as _build  # noqa: E402  (the package's build.py: one place for the compiler flags)
+HIPCC_FLAGS = [f for f in _build.FLAGS if f != "-Wall"]
 BLOCK = int(os.environ.get("UAV_BLOCK", 1024))
 LIB = os.path.join(ROOT, "gpurun_out", f"libuavenv_hip_stamps_b{BLOCK}.so")
 os.makedirs(os.path.dirname(LIB), exist_ok=True)
-subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+subprocess.check_call(["hipcc"] + HIPCC_FLAGS + [
                        "-DUAVENV_STAMPS", f"-DUAV_BLOCK={BLOCK}", "-o", LIB] + [os.path.join(PKG, "csrc", f) for f in
                        ("uavenv_kernels.hip", "uavenv_capi.hip", "uavenv_attention.hip")])
 import uavenv_amd  # noqa: E402
