@@ -280,7 +280,11 @@ static int upload_consts(UavEnv* e) {
 extern "C" int uavenv_set_seed(UavEnv* e, uint64_t seed) {
     if (!e) return UAVENV_E_INVALID;
     e->cfg.seed = seed; e->consts.seed = seed;
-    return upload_consts(e);
+    int rc = upload_consts(e);                              // synchronises the device
+    if (rc) return rc;
+    // the action words the last random-policy launch left behind were drawn with the old seed
+    HIP_TRY(e, hipMemset(e->hints, 0, 2 * (size_t)e->padded_envs * sizeof(uint32_t)));
+    return UAVENV_OK;
 }
 
 extern "C" int uavenv_set_grid_choices(UavEnv* e, int32_t count, const int32_t* w, const int32_t* h) {
@@ -399,6 +403,8 @@ extern "C" int uavenv_set_state(UavEnv* e, int32_t field, const void* src, size_
     void* dst = field_ptr(e, field);
     if (!dst) return fail(e, UAVENV_E_INVALID, "unknown state field");
     if (bytes != uavenv_state_bytes(e, field)) return fail(e, UAVENV_E_INVALID, "state field size mismatch");
+    // records may change under the action words of the last random-policy launch: drop them (they are re-drawn)
+    HIP_TRY(e, hipMemsetAsync(e->hints, 0, 2 * (size_t)e->padded_envs * sizeof(uint32_t), (hipStream_t)stream));
     HIP_TRY(e, hipMemcpyAsync(dst, src, bytes, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, (hipStream_t)stream));
     if (!src_on_device) HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream));
     return UAVENV_OK;

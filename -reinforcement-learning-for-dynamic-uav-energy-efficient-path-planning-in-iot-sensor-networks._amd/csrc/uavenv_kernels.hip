@@ -678,10 +678,16 @@ __global__ __launch_bounds__(kBlockThreads) void uav_reset_kernel(const Consts* 
 // global memory) and the fused rollout kernel (record staged in LDS, sensor state kept in registers
 // across steps).  `rec` may point to global memory or LDS.
 // ---------------------------------------------------------------------------------------------
+// Scheduling / action word the random-policy step leaves for the next launch: bits 0-2 the action of (episode, step),
+// bit 3 "valid", bits 4-19 step, bits 20-31 episode (low bits).  A launch uses the action of a word whose tag matches the
+// record it finds (else it draws the action itself: the word is an optimisation, never a source of truth), and every
+// launch uses "(word & 7) == 4" to spread the collect steps over the SIMDs.  0 = no information.
+__device__ __forceinline__ uint32_t hint_tag(uint32_t episode, uint32_t step) { return 8u | ((step & 0xFFFFu) << 4) | (episode << 20); }
+
 template <int G, bool kLean, bool kRegs = false, typename RecPtr = UavEnvRecord*, typename P = Ptrs, typename A = StepArgs>
 __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32_t env, bool in_batch,
                                           RecPtr rec, Sensor& s, bool& wrote_pos, uint32_t& status_or,
-                                          int& action_out) {
+                                          int& action_out, uint32_t hint_word = 0u) {
     const int gl = group_lane<G>();
     UAV_PHASE(0);
     Env e = load_env<G>(rec);
@@ -700,21 +706,10 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
 #ifdef UAV_ABL_CHEAPACTION   // timing-only ablation build: no Philox on the scalar unit for the action / the hint
         action = (int)((e.env_index * 7u + step * 3u + e.episode) % 5u);
 #else
-        Words4 w = noise_words(c.seed, e.env_index, e.episode, step, 0u, 3);
-        action = (int)(((uint64_t)w.w0 * 5u) >> 32);
+        if (G == 64 && (hint_word & ~7u) == hint_tag(e.episode, step)) action = (int)(hint_word & 7u);   // drawn last launch
+        else action = (int)(((uint64_t)noise_words(c.seed, e.env_index, e.episode, step, 0u, 3).w0 * 5u) >> 32);
 #endif
         if (a.actions_out != nullptr && in_batch && gl == 0) a.actions_out[env] = action;
-        // Scheduling hint for the NEXT launch (StepArgs::balance): will the following random action be a collect?
-        // Same draw one step ahead, on the scalar unit while the state loads are in flight (G = 64 only).  An
-        // episode that ends in this step makes the hint wrong, which costs balance for one launch, nothing else.
-        if (!kRegs && G == 64 && a.hint_out != nullptr) {
-#ifdef UAV_ABL_CHEAPACTION
-            if (gl == 0) a.hint_out[env] = ((e.env_index * 7u + (step + 1u) * 3u + e.episode) % 5u) == 4u ? 4u : 0u;
-#else
-            const Words4 w2 = noise_words(c.seed, e.env_index, e.episode, step + 1u, 0u, 3);
-            if (gl == 0) a.hint_out[env] = (uint32_t)(((uint64_t)w2.w0 * 5u) >> 32);       // the action itself: 4 = collect
-#endif
-        }
     }
     const bool is_c = action == 4;
     const bool is_m = (action >= 0) & (action <= 3);
@@ -1042,6 +1037,17 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
     }
     if (kRegs) *rec = r; else if (gl == 0) *rec = r;
     status_or |= r.status;
+    // The next launch's word: the action this environment draws next (after a possible auto-reset: exact), computed
+    // here, late, on the scalar unit -- off the critical path of the NEXT launch's wave start (G = 64 only).
+    if (!kRegs && G == 64 && a.hint_out != nullptr) {
+        const uint32_t ns = (uint32_t)(r.current_step + 1);
+#ifdef UAV_ABL_CHEAPACTION
+        const uint32_t na = (r.env_index * 7u + ns * 3u + r.episode) % 5u;
+#else
+        const uint32_t na = (uint32_t)(((uint64_t)noise_words(c.seed, r.env_index, r.episode, ns, 0u, 3).w0 * 5u) >> 32);
+#endif
+        if (gl == 0) a.hint_out[env] = na | hint_tag(r.episode, ns);
+    }
     UAV_PHASE(7);
 
     action_out = action;
@@ -1091,7 +1097,7 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_ker
         CU32 src = (from_actions ? (CU32)actions : (CU32)hint_in) + (size_t)blockIdx.x * kWords;
         uint32_t mask = 0u;
 #pragma unroll
-        for (int t = 0; t < kWords; t++) mask |= (src[t] == 4u ? 1u : 0u) << (t / kEnvsPerWave);
+        for (int t = 0; t < kWords; t++) mask |= ((src[t] & 7u) == 4u ? 1u : 0u) << (t / kEnvsPerWave);
         if (balance) {                                               // kernel-uniform
             const uint32_t full = kWaves >= 32 ? 0xFFFFFFFFu : ((1u << (kWaves & 31)) - 1u);
             const int nc = __popc(mask);
@@ -1108,7 +1114,10 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_ker
     bool wrote_pos = false;
     uint32_t status_or = 0u;
     int action = 0;
-    step_once<G, kLean>(c, p, a, env, in_batch, rec_base + env, s, wrote_pos, status_or, action);
+    uint32_t hint_word = 0u;
+    if (G == 64 && kWaves >= 4 && actions == nullptr)
+        hint_word = ((const __attribute__((address_space(4))) uint32_t*)hint_in)[blockIdx.x * kWaves + (uint32_t)unit];
+    step_once<G, kLean>(c, p, a, env, in_batch, rec_base + env, s, wrote_pos, status_or, action, hint_word);
     store_sensor<G>(sb, idx, s, wrote_pos);
     if (gl == 0 && status_or) atomicOr(p.status, status_or);
 #ifdef UAVENV_STAMPS

@@ -119,3 +119,33 @@ def test_simd_load_balancing_is_a_pure_scheduling_choice():
                                       env=dict(os.environ, UAVENV_NO_BALANCE=flag))
         outs.append([l for l in out.splitlines() if l.startswith("DIGEST")][0])
     assert outs[0] == outs[1]
+
+
+def test_action_words_never_outlive_the_seed_or_the_state():
+    """The random-policy step leaves the next launch the action it will draw (a word per environment, checked against
+    the record's episode/step before use).  Re-seeding, restoring state and fused rollouts must not let a stale word
+    decide an action: compare with an environment that has never seen those words."""
+    import torch
+    import uavenv_amd as U
+    kw = dict(num_sensors=50, max_steps=25)
+    a = U.BatchedUAVEnv(96, seed=1, **kw)
+    a.reset()
+    for _ in range(7):
+        a.step_random()
+    a.seed(7)                                            # words drawn with seed 1 are now wrong
+    b = U.BatchedUAVEnv(96, seed=7, **kw)
+    b.reset()
+    b.load_state_dict(a.state_dict())                    # same records / sensors, no words
+    for _ in range(30):                                  # crosses auto-resets (max_steps 25)
+        a.step_random(); b.step_random()
+        assert torch.equal(a.actions_taken, b.actions_taken) and torch.equal(a.obs, b.obs) and torch.equal(a.reward, b.reward)
+    # state restored to an EARLIER point: the words of the later point carry other (episode, step) tags or other actions
+    snap = a.state_dict()
+    for _ in range(3):
+        a.step_random()
+    a.load_state_dict(snap); b.load_state_dict(snap)
+    a.rollout(4); b.rollout(4)                           # the fused kernel neither reads nor writes words
+    for _ in range(5):
+        a.step_random(); b.step_random()
+        assert torch.equal(a.actions_taken, b.actions_taken) and torch.equal(a.obs, b.obs)
+    a.close(); b.close()
