@@ -88,6 +88,30 @@ class TransitionRing:
             self._env.set_aux_output(self.local_aux_slot())
         return slot
 
+    # ---- launch-bound producer loops: one HIP graph per ring revolution ---------------------------------
+    def capture_revolution(self, step_fn):
+        """Capture `capacity` consecutive `step_fn(obs_slot); commit()` pairs -- one full revolution of the ring,
+        starting at the current head -- into ONE HIP graph and return it.  `replay_revolution(graph)` then costs a
+        single graph launch instead of `capacity` Python -> ctypes -> hipLaunchKernel round trips (about 12 us each,
+        more than the step kernel itself at 4096 environments).  Single-rank rings only: the collective of a shared
+        ring is issued from the host.  `step_fn(obs_out)` must only enqueue work (e.g. `env.step_random`)."""
+        assert self.world == 1 and self.device.type == "cuda" and self._env is not None
+        head0, size0 = self.head, self.size
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(self.capacity):
+                step_fn(self.local_obs_slot())
+                self.commit()
+        # capturing executed nothing and the revolution ends where it began
+        assert self.head == head0
+        self.size = size0
+        return g
+
+    def replay_revolution(self, graph):
+        graph.replay()
+        self.size = self.capacity
+
     def drain(self):
         for s in range(self.capacity):
             self.wait_slot(s)

@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--exchange", choices=["auto", "none", "allgather"], default="auto")
     ap.add_argument("--ring", type=int, default=16, help="replay-ring slots used by the bench")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of replaying HIP graphs")
     ap.add_argument("--fused", type=int, default=16, help="steps per launch of the additional fused-rollout measurement (0 = skip)")
     args = ap.parse_args()
 
@@ -165,15 +166,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(W):
-        one_step()
+    # A Python -> ctypes -> hipLaunchKernel round trip costs ~12 us, more than the step kernel: without an exchange
+    # step the loop is captured, one ring revolution (`--ring` steps) per HIP graph, and replayed; steps that do not
+    # fill a revolution (and every step when ranks exchange blocks, whose collective is host-issued) launch eagerly.
+    graph = None
+    if exchange == "none" and not args.no_graph:
+        for _ in range(ring.capacity):   # bring the ring head (and the kernel's launch parity) to a revolution boundary
+            one_step()
+        graph = ring.capture_revolution(lambda slot: env.step_random(obs_out=slot))
+
+    def run_steps(n):
+        q, r = divmod(n, ring.capacity) if graph is not None else (0, n)
+        for _ in range(q):
+            ring.replay_revolution(graph)
+        for _ in range(r):
+            one_step()
+
+    run_steps(W)
     ring.drain()
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()                       # torch's current stream IS the stream the kernel is launched on
-    for _ in range(K):
-        one_step()
+    run_steps(K)
+    t_enq = time.perf_counter() - t0
     ev1.record()
     ring.drain()
     barrier()
@@ -229,6 +245,9 @@ def main():
                    "exchange": ("rccl all_gather of the transition block per step into a shared replay ring"
                                 if exchange == "allgather" else "none (observations written in place into the replay ring)"),
                    "parallelism": f"env-shard x{world}",
+                   "launch": (f"one step per kernel launch; launches replayed as HIP graphs of {ring.capacity} steps (one ring revolution)"
+                              if graph is not None else "one step per kernel launch, launched from Python"),
+                   "host_enqueue_us_per_step": t_enq / K * 1e6,
                    "arithmetic": "float64 state and rewards, float32 distance chain and observations (the reference's own mix)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS,
