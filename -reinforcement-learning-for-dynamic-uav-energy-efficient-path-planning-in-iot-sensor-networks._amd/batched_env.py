@@ -187,6 +187,16 @@ class BatchedUAVEnv:
         assert tuple(obs_out.shape) == (self.num_envs, self.obs_dim), tuple(obs_out.shape)
         return obs_out
 
+    def _hot_args(self, obs):
+        """(obs, reward, reward32, done, terminal_obs, stream) as plain integers: the per-step launches go through here,
+        and building eight ctypes objects per call costs more host time than the argument marshalling itself."""
+        fixed = self.__dict__.get("_fixed_ptrs")
+        if fixed is None or fixed[0] is not self.terminal_obs:
+            fixed = (self.terminal_obs, self.reward.data_ptr(), self.reward32.data_ptr(), self.done.data_ptr(),
+                     self.terminal_obs.data_ptr(), self.actions_taken.data_ptr())
+            self._fixed_ptrs = fixed
+        return fixed, obs.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream
+
     def step(self, actions, obs_out=None):
         """uav_env.py:429-488 for all E environments in one launch.
         actions: int32 cuda tensor [E].  Returns (obs, reward float64, done uint8); with auto_reset the
@@ -194,17 +204,19 @@ class BatchedUAVEnv:
         slot of a replay ring) written directly by the kernel instead of `self.obs`."""
         assert actions.is_cuda and actions.dtype == torch.int32 and actions.numel() == self.num_envs
         obs = self._obs_target(obs_out)
-        N.check(self.L.uavenv_step(self._h, self._p(actions), self._p(obs), self._p(self.reward),
-                                   self._p(self.reward32), self._p(self.done), self._p(self.terminal_obs),
-                                   self._stream()), self._h)
+        f, po, st = self._hot_args(obs)
+        rc = self.L.uavenv_step(self._h, actions.data_ptr(), po, f[1], f[2], f[3], f[4], st)
+        if rc:
+            N.check(rc, self._h)
         return obs, self.reward, self.done
 
     def step_random(self, obs_out=None):
         """Same with the uniform-random policy drawn in-kernel; the actions land in `self.actions_taken`."""
         obs = self._obs_target(obs_out)
-        N.check(self.L.uavenv_step_random(self._h, self._p(self.actions_taken), self._p(obs), self._p(self.reward),
-                                          self._p(self.reward32), self._p(self.done), self._p(self.terminal_obs),
-                                          self._stream()), self._h)
+        f, po, st = self._hot_args(obs)
+        rc = self.L.uavenv_step_random(self._h, f[5], po, f[1], f[2], f[3], f[4], st)
+        if rc:
+            N.check(rc, self._h)
         return obs, self.reward, self.done
 
     def step_policy(self, policy, obs_out=None):
