@@ -300,7 +300,16 @@ struct Env {
     double inv_w, inv_h;
 };
 template <int G> __device__ __forceinline__ int uni(int v) { return G == 64 ? __builtin_amdgcn_readfirstlane(v) : v; }
-template <int G> __device__ __forceinline__ Env load_env(const UavEnvRecord* rp) {
+// whole-record read: a plain copy, or word by word through the constant address space (scalar loads -> SGPRs)
+__device__ __forceinline__ UavEnvRecord load_record(const UavEnvRecord* rp) { return *rp; }
+__device__ __forceinline__ UavEnvRecord load_record(const __attribute__((address_space(4))) UavEnvRecord* rp) {
+    union { UavEnvRecord r; uint32_t w[32]; } u;
+    const __attribute__((address_space(4))) uint32_t* wp = (const __attribute__((address_space(4))) uint32_t*)rp;
+#pragma unroll
+    for (int i = 0; i < 32; i++) u.w[i] = wp[i];
+    return u.r;
+}
+template <int G, typename RP> __device__ __forceinline__ Env load_env(RP rp) {
     Env e;
     double b = rp->battery;
     e.battery = __hiloint2double(uni<G>(__double2hiint(b)), uni<G>(__double2loint(b)));
@@ -686,7 +695,7 @@ __device__ __forceinline__ uint32_t hint_tag(uint32_t episode, uint32_t step) { 
 
 template <int G, bool kLean, bool kRegs = false, typename RecPtr = UavEnvRecord*, typename P = Ptrs, typename A = StepArgs>
 __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32_t env, bool in_batch,
-                                          RecPtr rec, Sensor& s, bool& wrote_pos, uint32_t& status_or,
+                                          RecPtr rec, UavEnvRecord* rec_out, Sensor& s, bool& wrote_pos, uint32_t& status_or,
                                           int& action_out, uint32_t hint_word = 0u) {
     const int gl = group_lane<G>();
     UAV_PHASE(0);
@@ -962,9 +971,9 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
 
     // ---- epilogue: the cold part of the record (read late on purpose: see struct Env) -----------------
     asm volatile("" ::: "memory");
-    UavEnvRecord r = *rec;
+    UavEnvRecord r = load_record(rec);
     UAV_PHASE(6);
-    if (G == 64) {      // wave-uniform: keep the record in SGPRs (matters when `rec` is LDS: ds_read lands in VGPRs)
+    if (G == 64 && kRegs) {   // wave-uniform: keep the record in SGPRs (the single-step kernel reads it with scalar loads)
         union { UavEnvRecord r; int w[32]; } u;
         u.r = r;
 #pragma unroll
@@ -1035,7 +1044,7 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
         }
         wrote_pos |= draw_layout && do_reset;
     }
-    if (kRegs) *rec = r; else if (gl == 0) *rec = r;
+    if (kRegs) *rec_out = r; else if (gl == 0) *rec_out = r;
     status_or |= r.status;
     // The next launch's word: the action this environment draws next (after a possible auto-reset: exact), computed
     // here, late, on the scalar unit -- off the critical path of the NEXT launch's wave start (G = 64 only).
@@ -1117,7 +1126,14 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_ker
     uint32_t hint_word = 0u;
     if (G == 64 && kWaves >= 4 && actions == nullptr)
         hint_word = ((const __attribute__((address_space(4))) uint32_t*)hint_in)[blockIdx.x * kWaves + (uint32_t)unit];
-    step_once<G, kLean>(c, p, a, env, in_batch, rec_base + env, s, wrote_pos, status_or, action, hint_word);
+    // G = 64: the record is wave-uniform and nobody else touches it during the launch, so it is read with scalar loads
+    // (constant address space: straight into SGPRs, no v_readfirstlane) and written once by lane 0 at the end.
+    if (G == 64) {
+        typedef const __attribute__((address_space(4))) UavEnvRecord* ScalarRec;
+        step_once<G, kLean, false, ScalarRec>(c, p, a, env, in_batch, (ScalarRec)(rec_base + env), rec_base + env, s, wrote_pos,
+                                              status_or, action, hint_word);
+    } else
+        step_once<G, kLean>(c, p, a, env, in_batch, rec_base + env, rec_base + env, s, wrote_pos, status_or, action, hint_word);
     store_sensor<G>(sb, idx, s, wrote_pos);
     if (gl == 0 && status_or) atomicOr(p.status, status_or);
 #ifdef UAVENV_STAMPS
@@ -1169,7 +1185,7 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_rollout_
         const Consts* cp = cptr;
         asm volatile("" : "+s"(cp));
         CRef ck = *(const __attribute__((address_space(4))) Consts*)(cp);
-        step_once<G, kLean, true>(ck, p, ak, env, in_batch, &rr, s, wrote_pos, status_or, action);
+        step_once<G, kLean, true>(ck, p, ak, env, in_batch, &rr, &rr, s, wrote_pos, status_or, action);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
