@@ -20,15 +20,28 @@ import torch.distributed as dist
 
 
 class TransitionRing:
-    def __init__(self, capacity, envs_per_rank, obs_dim, device, world_size=1, rank=0, group=None, terminal_rows=None):
+    def __init__(self, capacity, envs_per_rank, obs_dim, device, world_size=1, rank=0, group=None, terminal_rows=None,
+                 chunk_len=1, always_exchange=False):
+        """chunk_len: slots per exchange.  1 = every commit() all-gathers its slot in place.  L > 1 = the ring is
+        split into capacity/L chunks and a chunk is gathered (one in-place collective of L blocks per rank) when its last
+        slot is committed: L times fewer, L times larger collectives -- at ~10 us per step the per-call host cost of a
+        collective is several steps long -- and the natural unit for HIP-graph replay (`capture_chunks`)."""
         self.capacity, self.E, self.D = int(capacity), int(envs_per_rank), int(obs_dim)
+        self.L = int(chunk_len)
+        assert self.L >= 1 and self.capacity % self.L == 0
+        self.n_chunks = self.capacity // self.L
         self.world, self.rank, self.group = int(world_size), int(rank), group
+        self.exchange = self.world > 1 or bool(always_exchange)   # always_exchange: run the collective even alone (self-test)
         self.device = torch.device(device)
-        # [slot][rank][block]: a rank's block (obs then aux) is contiguous => ONE in-place all-gather per step
+        # [chunk][rank][slot in chunk][block]: a rank's part of a chunk (L blocks, each obs then aux) is contiguous and
+        # the chunk is the concatenation of the ranks' parts => ONE in-place all-gather per chunk
         self.block = self.E * (self.D + 4)
-        self.store = torch.zeros(self.capacity, self.world, self.block, dtype=torch.float32, device=self.device)
-        self.obs = self.store[:, :, :self.E * self.D].view(self.capacity, self.world, self.E, self.D)
-        self.aux = self.store[:, :, self.E * self.D:].view(self.capacity, self.world, self.E, 4)
+        self.store = torch.zeros(self.n_chunks, self.world, self.L, self.block, dtype=torch.float32, device=self.device)
+        self._obs5 = self.store[..., :self.E * self.D].view(self.n_chunks, self.world, self.L, self.E, self.D)
+        self._aux5 = self.store[..., self.E * self.D:].view(self.n_chunks, self.world, self.L, self.E, 4)
+        if self.L == 1:      # the plain [slot][rank][env] views
+            self.obs = self._obs5.view(self.capacity, self.world, self.E, self.D)
+            self.aux = self._aux5.view(self.capacity, self.world, self.E, 4)
         # terminal-observation pool (rows recycle; sized so that a row outlives the ring slot that refers to it:
         # ~E/1400 episodes end per step)
         self.terminal_rows = int(terminal_rows) if terminal_rows is not None else max(1024, (self.capacity * self.E) // 256)
@@ -37,7 +50,7 @@ class TransitionRing:
         self._env = None
         self.head = 0                 # next slot to write
         self.size = 0                 # number of valid slots
-        self._pending = [None] * self.capacity
+        self._pending = [None] * self.n_chunks     # outstanding collective per chunk
         self._comm_stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
 
     def attach(self, env):
@@ -48,73 +61,107 @@ class TransitionRing:
         env.set_aux_output(self.local_aux_slot())
 
     # ---- producer side -----------------------------------------------------------------------
+    def _cj(self, slot):
+        return slot // self.L, slot % self.L
+
+    def obs_at(self, slot, r, e):
+        """Observation rows by (slot, rank, env) index tensors (or ints / slices)."""
+        return self._obs5[slot // self.L, r, slot % self.L, e]
+
+    def aux_at(self, slot, r, e):
+        return self._aux5[slot // self.L, r, slot % self.L, e]
+
     def local_obs_slot(self, slot=None):
         """[E, D] view of THIS rank's part of a slot: pass it as `obs_out` to BatchedUAVEnv.step*()."""
-        return self.obs[self.head if slot is None else slot, self.rank]
+        c, j = self._cj(self.head if slot is None else slot)
+        return self._obs5[c, self.rank, j]
 
     def local_aux_slot(self, slot=None):
-        return self.aux[self.head if slot is None else slot, self.rank]
+        c, j = self._cj(self.head if slot is None else slot)
+        return self._aux5[c, self.rank, j]
 
-    def wait_slot(self, slot):
-        w = self._pending[slot]
+    def wait_chunk(self, c):
+        w = self._pending[c]
         if w is not None:
             w.wait()
-            self._pending[slot] = None
+            self._pending[c] = None
+
+    def wait_slot(self, slot):
+        self.wait_chunk(slot // self.L)
+
+    def _gather_chunk(self, c):
+        """One in-place all-gather of this rank's L blocks of chunk c (RCCL on a side stream / gloo on CPU)."""
+        out, inp = self.store[c].view(-1), self.store[c, self.rank].view(-1)
+        if self._comm_stream is not None:
+            self._comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self._comm_stream):
+                w = dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
+        else:   # CPU / gloo (tests)
+            w = dist.all_gather_into_tensor(out, inp.clone(), group=self.group, async_op=True)
+        self._pending[c] = w
+
+    def _advance(self, n):
+        """Move the head by n committed slots; gather every chunk that was completed; make sure the chunk the head
+        enters next is no longer being gathered."""
+        for _ in range(n):
+            slot = self.head
+            c, j = self._cj(slot)
+            if self.exchange and j == self.L - 1:
+                self._gather_chunk(c)
+            self.head = (slot + 1) % self.capacity
+            self.size = min(self.size + 1, self.capacity)
+        self.wait_slot(self.head)
 
     def commit(self, actions=None, reward=None, done=None):
         """Publish this rank's block of the current slot.  With an attached env the kernel has already written
         the aux part; otherwise (tests, foreign producers) pass actions / reward / done to fill it here."""
         slot = self.head
         if actions is not None:
-            aux = self.aux[slot, self.rank]
+            aux = self.local_aux_slot(slot)
             aux[:, 0] = actions.to(torch.float32)
             aux[:, 1] = reward.to(torch.float32)
             aux[:, 2] = done.to(torch.float32)
             aux[:, 3] = -1.0
-        if self.world > 1:
-            out, inp = self.store[slot].view(-1), self.store[slot, self.rank]
-            if self._comm_stream is not None:
-                self._comm_stream.wait_stream(torch.cuda.current_stream(self.device))
-                with torch.cuda.stream(self._comm_stream):
-                    w = dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
-            else:   # CPU / gloo (tests)
-                w = dist.all_gather_into_tensor(out, inp.clone(), group=self.group, async_op=True)
-            self._pending[slot] = w
-        self.head = (slot + 1) % self.capacity
-        self.size = min(self.size + 1, self.capacity)
-        # the slot about to be overwritten next must have finished its previous gather
-        self.wait_slot(self.head)
+        self._advance(1)
         if self._env is not None:
             self._env.set_aux_output(self.local_aux_slot())
         return slot
 
-    # ---- launch-bound producer loops: one HIP graph per ring revolution ---------------------------------
-    def capture_revolution(self, step_fn):
-        """Capture `capacity` consecutive `step_fn(obs_slot); commit()` pairs -- one full revolution of the ring,
-        starting at the current head -- into ONE HIP graph and return it.  `replay_revolution(graph)` then costs a
-        single graph launch instead of `capacity` Python -> ctypes -> hipLaunchKernel round trips (about 12 us each,
-        more than the step kernel itself at 4096 environments).  Single-rank rings only: the collective of a shared
-        ring is issued from the host.  `step_fn(obs_out)` must only enqueue work (e.g. `env.step_random`)."""
-        assert self.world == 1 and self.device.type == "cuda" and self._env is not None
-        head0, size0 = self.head, self.size
+    # ---- launch-bound producer loops: one HIP graph per chunk -----------------------------------------------
+    def capture_chunks(self, step_fn):
+        """Capture, for every chunk, its L consecutive `step_fn(obs_slot); (aux re-pointing)` launches into one HIP graph
+        (the head must stand at the start of a chunk).  `replay_chunk(graphs)` then costs one graph launch (plus the
+        chunk's collective when ranks share the ring, issued from the host after the replay) instead of L Python ->
+        ctypes -> hipLaunchKernel round trips of ~12 us each -- more than the step kernel itself at 4096 environments.
+        `step_fn(obs_out)` must only enqueue work on the current stream (e.g. `env.step_random`)."""
+        assert self.device.type == "cuda" and self._env is not None and self.head % self.L == 0
+        self.drain()
         torch.cuda.synchronize(self.device)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for _ in range(self.capacity):
-                step_fn(self.local_obs_slot())
-                self.commit()
-        # capturing executed nothing and the revolution ends where it began
-        assert self.head == head0
-        self.size = size0
-        return g
+        head0, graphs = self.head, [None] * self.n_chunks
+        for k in range(self.n_chunks):
+            c = (head0 // self.L + k) % self.n_chunks
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for j in range(self.L):
+                    slot = c * self.L + j
+                    self._env.set_aux_output(self.local_aux_slot(slot))
+                    step_fn(self.local_obs_slot(slot))
+            graphs[c] = g
+        self._env.set_aux_output(self.local_aux_slot())          # capturing executed nothing
+        return graphs
 
-    def replay_revolution(self, graph):
-        graph.replay()
-        self.size = self.capacity
+    def replay_chunk(self, graphs):
+        """Replay the graph of the chunk at the head and commit its L slots."""
+        c = self.head // self.L
+        assert self.head % self.L == 0
+        self.wait_chunk(c)            # its previous gather (a full revolution ago) must be done before it is overwritten;
+        graphs[c].replay()            # the gather of the chunk just before this one keeps running on the side stream
+        self._advance(self.L)
+        self._env.set_aux_output(self.local_aux_slot())
 
     def drain(self):
-        for s in range(self.capacity):
-            self.wait_slot(s)
+        for c in range(self.n_chunks):
+            self.wait_chunk(c)
         if self._comm_stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(self._comm_stream)
 
@@ -130,11 +177,11 @@ class TransitionRing:
     def _next_frame(self, slot, r, e):
         """(action, reward, done, newest frame of next_obs, valid) of the transitions slot -> slot+1."""
         nxt = (slot + 1) % self.capacity
-        aux = self.aux[nxt, r, e]                  # the aux row stored WITH an observation describes the step INTO it
+        aux = self.aux_at(nxt, r, e)               # the aux row stored WITH an observation describes the step INTO it
         done = aux[:, 2] > 0.5
         tidx = aux[:, 3].long()
         have_term = done & (tidx >= 0) & (r == self.rank)
-        last = torch.where(have_term.unsqueeze(1), self.term_pool[tidx.clamp(min=0)], self.obs[nxt, r, e])
+        last = torch.where(have_term.unsqueeze(1), self.term_pool[tidx.clamp(min=0)], self.obs_at(nxt, r, e))
         return aux[:, 0].long(), aux[:, 1], done, last, ~done | have_term
 
     def sample(self, batch_size, generator=None):
@@ -145,7 +192,7 @@ class TransitionRing:
         self.drain()
         _, slot, r, e = self._draw(batch_size, generator)
         action, reward, done, last, valid = self._next_frame(slot, r, e)
-        return dict(obs=self.obs[slot, r, e], action=action, reward=reward, done=done, next_obs=last, valid=valid)
+        return dict(obs=self.obs_at(slot, r, e), action=action, reward=reward, done=done, next_obs=last, valid=valid)
 
     def sample_stacked(self, batch_size, n_stack, generator=None):
         """Like sample(), but observations are frame stacks of `n_stack` frames gathered from the ring on the
@@ -160,8 +207,8 @@ class TransitionRing:
         fs = (slot.unsqueeze(1) - back.unsqueeze(0)) % self.capacity                # [B, k] frame slots
         in_ring = (j.unsqueeze(1) - back.unsqueeze(0)) >= 0                         # frame older than the ring start?
         rr, ee = r.unsqueeze(1).expand(-1, k), e.unsqueeze(1).expand(-1, k)
-        frames = self.obs[fs, rr, ee]                                               # [B, k, D]
-        dn = self.aux[fs, rr, ee, 2] > 0.5                                          # frame is the first of an episode
+        frames = self.obs_at(fs, rr, ee)                                            # [B, k, D]
+        dn = self.aux_at(fs, rr, ee)[..., 2] > 0.5                                  # frame is the first of an episode
         # frame i (i < k-1) is valid iff no episode start among frames i+1 .. k-1
         later_start = torch.flip(torch.cumsum(torch.flip(dn[:, 1:], [1]).int(), 1), [1]) > 0     # [B, k-1]
         valid_f = torch.cat([~later_start, torch.ones(batch_size, 1, dtype=torch.bool, device=self.device)], 1) & in_ring

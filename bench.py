@@ -101,7 +101,7 @@ def main():
     ap.add_argument("--sensors", type=int, default=50)
     ap.add_argument("--grid", type=int, default=500)
     ap.add_argument("--exchange", choices=["auto", "none", "allgather"], default="auto")
-    ap.add_argument("--ring", type=int, default=16, help="replay-ring slots used by the bench")
+    ap.add_argument("--ring", type=int, default=32, help="replay-ring slots used by the bench (two chunks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of replaying HIP graphs")
     ap.add_argument("--fused", type=int, default=16, help="steps per launch of the additional fused-rollout measurement (0 = skip)")
@@ -119,7 +119,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    distributed = world > 1
+    selftest = os.environ.get("UAVENV_BENCH_SELFTEST_DIST") == "1"     # dev: run the N>1 code path on one rank
+    distributed = world > 1 or selftest
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -135,17 +136,25 @@ def main():
         exchange = "allgather" if distributed else "none"
     if not distributed:
         exchange = "none"
-    ring = TransitionRing(args.ring, E, env.obs_dim, dev, world_size=world if exchange == "allgather" else 1,
-                          rank=rank if exchange == "allgather" else 0)
-    ring.attach(env)      # the kernel writes obs AND (action, reward, done, terminal row) straight into the ring slot
+    use_graph = not args.no_graph
+    L = max(1, args.ring // 2) if use_graph else 1       # slots per chunk = per HIP graph = per collective
+
+    def make_ring(shared):
+        r_ = TransitionRing(args.ring, E, env.obs_dim, dev, world_size=world if shared else 1, rank=rank if shared else 0,
+                            chunk_len=L, always_exchange=shared and selftest)
+        r_.attach(env)    # the kernel writes obs AND (action, reward, done, terminal row) straight into the ring slot
+        return r_
+
+    ring = make_ring(exchange == "allgather")
     env.reset()
     exchange_error = None
     if exchange == "allgather":
         # One probe exchange before anything is timed: if the collective cannot run on this node, say so in the
         # JSON line and measure the shards without it rather than dying without a result.
         try:
-            env.step_random(obs_out=ring.local_obs_slot())
-            ring.commit()
+            for _ in range(L):
+                env.step_random(obs_out=ring.local_obs_slot())
+                ring.commit()                     # the L-th commit completes a chunk and issues its all-gather
             ring.drain()
             torch.cuda.synchronize(dev)
         except Exception as ex:          # pragma: no cover - depends on the node
@@ -154,8 +163,7 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if int(flag.item()):
             exchange = "none"
-            ring = TransitionRing(args.ring, E, env.obs_dim, dev, world_size=1, rank=0)
-            ring.attach(env)
+            ring = make_ring(False)
 
     def one_step():
         env.step_random(obs_out=ring.local_obs_slot())
@@ -166,23 +174,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # A Python -> ctypes -> hipLaunchKernel round trip costs ~12 us, more than the step kernel: without an exchange
-    # step the loop is captured, one ring revolution (`--ring` steps) per HIP graph, and replayed; steps that do not
-    # fill a revolution (and every step when ranks exchange blocks, whose collective is host-issued) launch eagerly.
-    graph = None
-    if exchange == "none" and not args.no_graph:
-        for _ in range(ring.capacity):   # bring the ring head (and the kernel's launch parity) to a revolution boundary
+    # A Python -> ctypes -> hipLaunchKernel round trip costs ~12 us, more than the step kernel, and a collective call
+    # several times that: the loop is captured, one chunk of the ring (`--ring`/2 steps) per HIP graph, and replayed;
+    # ranks that share the ring all-gather a chunk (one in-place RCCL collective of L transition blocks per rank, side
+    # stream, overlapping the next chunk's steps) when it is complete.  Steps that do not fill a chunk launch eagerly.
+    graphs = None
+    if use_graph:
+        while ring.head % L:
             one_step()
-        graph = ring.capture_revolution(lambda slot: env.step_random(obs_out=slot))
+        graphs = ring.capture_chunks(lambda slot: env.step_random(obs_out=slot))
 
-    def run_steps(n):
-        q, r = divmod(n, ring.capacity) if graph is not None else (0, n)
+    def run_steps(n, align=False):
+        q, r = divmod(n, L) if graphs is not None else (0, n)
         for _ in range(q):
-            ring.replay_revolution(graph)
+            ring.replay_chunk(graphs)
         for _ in range(r):
             one_step()
+        while align and graphs is not None and ring.head % L:      # untimed: back to a chunk boundary
+            one_step()
 
-    run_steps(W)
+    run_steps(W, align=True)
     ring.drain()
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -242,11 +253,11 @@ def main():
         "config": {"workload": f"{E} envs/GPU x {n} sensors, {args.grid}x{args.grid} grid, BASE_ENV_CONFIG, "
                                f"uniform-random policy (in-kernel Philox), auto-reset, obs+reward+done written every step",
                    "envs_per_gpu": E, "sensors": n, "grid": args.grid, "obs_dim": env.obs_dim,
-                   "exchange": ("rccl all_gather of the transition block per step into a shared replay ring"
+                   "exchange": (f"one in-place rccl all_gather per {L} steps of every rank's {L} transition blocks into a shared replay ring"
                                 if exchange == "allgather" else "none (observations written in place into the replay ring)"),
                    "parallelism": f"env-shard x{world}",
-                   "launch": (f"one step per kernel launch; launches replayed as HIP graphs of {ring.capacity} steps (one ring revolution)"
-                              if graph is not None else "one step per kernel launch, launched from Python"),
+                   "launch": (f"one step per kernel launch; launches replayed as HIP graphs of {L} steps (one ring chunk)"
+                              if graphs is not None else "one step per kernel launch, launched from Python"),
                    "host_enqueue_us_per_step": t_enq / K * 1e6,
                    "arithmetic": "float64 state and rewards, float32 distance chain and observations (the reference's own mix)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -151,40 +151,45 @@ def test_action_words_never_outlive_the_seed_or_the_state():
     a.close(); b.close()
 
 
-def test_ring_revolution_graph_equals_the_eager_loop():
-    """TransitionRing.capture_revolution: one HIP graph per ring revolution (the bench's launch path) produces the
-    same ring contents, terminal pool and environment state as stepping from Python."""
+def test_ring_chunk_graphs_equal_the_eager_loop():
+    """TransitionRing.capture_chunks: one HIP graph per ring chunk (the bench's launch path) produces the same ring
+    contents, terminal pool and environment state as stepping from Python."""
     import torch
     import uavenv_amd as U
     from uavenv_amd.replay import TransitionRing
     kw = dict(num_sensors=20, seed=3, max_steps=11)
     envs, rings = [], []
-    for _ in range(2):
+    for chunk in (1, 4):
         e = U.BatchedUAVEnv(300, **kw)
-        r = TransitionRing(8, 300, e.obs_dim, e.device, terminal_rows=4096)
+        r = TransitionRing(8, 300, e.obs_dim, e.device, terminal_rows=4096, chunk_len=chunk)
         r.attach(e); e.reset()
         envs.append(e); rings.append(r)
     (ea, eb), (ra, rb) = envs, rings
-    for _ in range(8):                                   # both at a revolution boundary
+    for _ in range(8):                                   # both at a chunk boundary
         ea.step_random(obs_out=ra.local_obs_slot()); ra.commit()
         eb.step_random(obs_out=rb.local_obs_slot()); rb.commit()
-    g = rb.capture_revolution(lambda slot: eb.step_random(obs_out=slot))
+    graphs = rb.capture_chunks(lambda slot: eb.step_random(obs_out=slot))
+    all_e = torch.arange(300, device=ea.device)
     for rev in range(3):
         for _ in range(8):
             ea.step_random(obs_out=ra.local_obs_slot()); ra.commit()
-        rb.replay_revolution(g)
+        rb.replay_chunk(graphs); rb.replay_chunk(graphs)
         torch.cuda.synchronize()
         assert ra.size == rb.size == 8 and ra.head == rb.head
-        assert torch.equal(ra.obs, rb.obs) and torch.equal(ra.aux[..., :3], rb.aux[..., :3])
         # terminal-pool rows are handed out by an atomic counter (order of arrival): compare what the rows hold
         assert int(ra.term_counter.item()) == int(rb.term_counter.item()) > 0
-        rows_a, rows_b = ra.aux[..., 3].long(), rb.aux[..., 3].long()
-        assert torch.equal(rows_a >= 0, rows_b >= 0)
-        m = rows_a >= 0
-        if bool(m.any()):
-            assert torch.equal(ra.term_pool[rows_a[m]], rb.term_pool[rows_b[m]])
+        for slot in range(8):
+            aa, ab = ra.aux_at(slot, 0, all_e), rb.aux_at(slot, 0, all_e)
+            assert torch.equal(ra.obs_at(slot, 0, all_e), rb.obs_at(slot, 0, all_e)) and torch.equal(aa[:, :3], ab[:, :3])
+            rows_a, rows_b = aa[:, 3].long(), ab[:, 3].long()
+            assert torch.equal(rows_a >= 0, rows_b >= 0)
+            m = rows_a >= 0
+            if bool(m.any()):
+                assert torch.equal(ra.term_pool[rows_a[m]], rb.term_pool[rows_b[m]])
     sa, sb = ea.state_dict(), eb.state_dict()
     assert all(torch.equal(sa[k], sb[k]) for k in sa)
     batch = rb.sample(256)
     assert batch["obs"].shape == (256, eb.obs_dim) and bool(batch["valid"].all())
+    batch = rb.sample_stacked(64, 4)
+    assert batch["obs"].shape == (64, 4 * eb.obs_dim)
     ea.close(); eb.close()

@@ -96,6 +96,26 @@ def _ring_worker(rank, world, port, q):
             ok &= bool(torch.equal(ring.aux[slot, r, :, 1], torch.full((E,), float(s))))
     b = ring.sample(32)
     ok &= b["obs"].shape == (32, D)
+    # chunked exchange (bench.py with N > 1): one collective per chunk of 4 slots, issued when the chunk is complete
+    ring = TransitionRing(8, E, D, "cpu", world_size=world, rank=rank, chunk_len=4)
+    other = 1 - rank
+    for s in range(12):
+        mine = torch.arange(E * D, dtype=torch.float32).reshape(E, D) + 1000 * rank + 100 * s
+        ring.local_obs_slot().copy_(mine)
+        slot = ring.commit(torch.full((E,), rank), torch.full((E,), float(s)), torch.zeros(E))
+        ring.drain()
+        all_e = torch.arange(E)
+        if slot % 4 == 3:                                # chunk complete: every rank's four blocks are here
+            for back in range(4):
+                for r in range(world):
+                    want = torch.arange(E * D, dtype=torch.float32).reshape(E, D) + 1000 * r + 100 * (s - back)
+                    ok &= bool(torch.equal(ring.obs_at(slot - back, r, all_e), want))
+                    ok &= bool(torch.equal(ring.aux_at(slot - back, r, all_e)[:, 1], torch.full((E,), float(s - back))))
+        else:                                            # mid-chunk: the other rank's block of this slot is not in yet
+            stale = torch.arange(E * D, dtype=torch.float32).reshape(E, D) + 1000 * other + 100 * s
+            ok &= not bool(torch.equal(ring.obs_at(slot, other, all_e), stale))
+    b = ring.sample(32)
+    ok &= b["obs"].shape == (32, D) and ring.size == 8
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, ok))
