@@ -18,6 +18,9 @@ namespace uavenv {
 // (tools/wave_map.py): the step kernel deals the expensive collect-action environments of a workgroup round-robin over
 // the four SIMDs (StepArgs::balance).
 constexpr int kBlockThreads = UAV_BLOCK;
+// Every other kernel, and the step kernel on batches too small to give each CU 16 waves, uses 4-wave workgroups (they
+// spread over more CUs); the padding granule stays kBlockThreads / G environments, which both sizes divide.
+constexpr int kSmallBlockThreads = 256;
 
 // flag word per sensor (UAVENV_F_FLAGS)
 constexpr uint32_t kSfMask = 15u, kAvgValid = 16u, kVisited = 32u, kDataCollected = 64u;
@@ -112,6 +115,7 @@ struct ResetArgs {
 hipError_t launch_init(int G, int padded_envs, const Consts& c, const Consts* dev_consts, const Ptrs& p, uint32_t env_index_base,
                        int32_t grid_w, int32_t grid_h, int32_t n, float start_x, float start_y, hipStream_t s);
 hipError_t launch_reset(int G, int padded_envs, const Consts& c, const Consts* dev_consts, const Ptrs& p, const ResetArgs& a, hipStream_t s);
+bool step_uses_big_workgroups(int G, int padded_envs);   // 16-wave workgroups + SIMD load balancing, else 4-wave
 hipError_t launch_step(int G, int padded_envs, const Consts& c, const Consts* dev_consts, const Ptrs& p, const StepArgs& a, hipStream_t s);
 hipError_t launch_rollout(int G, int padded_envs, const Consts& c, const Consts* dev_consts, const Ptrs& p, const StepArgs& a,
                           int32_t num_steps, hipStream_t s);

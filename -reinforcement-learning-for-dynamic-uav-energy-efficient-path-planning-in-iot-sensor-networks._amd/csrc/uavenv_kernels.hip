@@ -614,12 +614,12 @@ __device__ __forceinline__ void far_start(CRef c, const Sensor& s, UavEnvRecord&
 // init kernel: records + (optionally) Philox sensor layouts, no episode started
 // ---------------------------------------------------------------------------------------------
 template <int G>
-__global__ __launch_bounds__(kBlockThreads) void uav_init_kernel(const Consts* cptr, Ptrs p, uint32_t env_index_base,
+__global__ __launch_bounds__(kSmallBlockThreads) void uav_init_kernel(const Consts* cptr, Ptrs p, uint32_t env_index_base,
                                                                  int32_t grid_w, int32_t grid_h, int32_t n,
                                                                  float start_x, float start_y) {
     UAV_CONSTS(cptr);
     const int gl = group_lane<G>();
-    const uint32_t env = blockIdx.x * (kBlockThreads / G) + threadIdx.x / G;
+    const uint32_t env = blockIdx.x * (kSmallBlockThreads / G) + threadIdx.x / G;
     const uint32_t idx = env * G + gl;
     uint32_t gidx = env_index_base + env;
     Words4 w = noise_words(c.seed, gidx, 0xFFFFFFFFu, 0u, (uint32_t)gl, 2);
@@ -649,11 +649,11 @@ __global__ __launch_bounds__(kBlockThreads) void uav_init_kernel(const Consts* c
 // reset kernel
 // ---------------------------------------------------------------------------------------------
 template <int G>
-__global__ __launch_bounds__(kBlockThreads) void uav_reset_kernel(const Consts* cptr, Ptrs p, ResetArgs a) {
+__global__ __launch_bounds__(kSmallBlockThreads) void uav_reset_kernel(const Consts* cptr, Ptrs p, ResetArgs a) {
     constexpr bool kLean = false;
     UAV_CONSTS(cptr);
     const int gl = group_lane<G>();
-    const uint32_t env = blockIdx.x * (kBlockThreads / G) + threadIdx.x / G;
+    const uint32_t env = blockIdx.x * (kSmallBlockThreads / G) + threadIdx.x / G;
     const uint32_t idx = env * G + gl;
 
     UavEnvRecord r = p.rec[env];
@@ -1065,8 +1065,8 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
 // ---------------------------------------------------------------------------------------------
 // step kernel: one launch = one step() of every environment
 // ---------------------------------------------------------------------------------------------
-template <int G, bool kLean>
-__global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_kernel(
+template <int G, bool kLean, int kWaves>
+__global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kernel(
         // The first seven arguments repeat fields of the two structs: they are the pointers the first loads of a wave
         // need, and as leading scalar arguments they arrive PRELOADED in SGPRs with the wave launch (gfx950 kernarg
         // preload, -mllvm -amdgpu-kernarg-preload-count=7 in build.py) instead of behind a kernarg-segment round trip.
@@ -1091,10 +1091,10 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_ker
     // ---- which environments does this wavefront step?  Home mapping: wave w takes unit w (= 64/G consecutive
     // environments).  Balanced mapping: units holding a collect action first, so that the collect steps of this
     // workgroup are dealt round-robin over the SIMDs (waves w, w+4, w+8, w+12 share one).
-    constexpr int kWaves = kBlockThreads / 64, kEnvsPerWave = 64 / G;
+    constexpr int kEnvsPerWave = 64 / G;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int unit = wave;
-    if (kWaves >= 4) {
+    if (kWaves >= 8) {          // 4-wave workgroups: one wave per SIMD, nothing to deal
         // One word per environment of this workgroup, "== 4" meaning "steps a collect action": the caller's action
         // array, or for the in-kernel random policy the words the PREVIOUS launch left in hint_in (one step ahead draw).
         // Fetched with ONE scalar load whose address needs only preloaded arguments and the workgroup id, so it is
@@ -1124,7 +1124,7 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_ker
     uint32_t status_or = 0u;
     int action = 0;
     uint32_t hint_word = 0u;
-    if (G == 64 && kWaves >= 4 && actions == nullptr)
+    if (G == 64 && kWaves >= 8 && actions == nullptr)
         hint_word = ((const __attribute__((address_space(4))) uint32_t*)hint_in)[blockIdx.x * kWaves + (uint32_t)unit];
     // G = 64: the record is wave-uniform and nobody else touches it during the launch, so it is read with scalar loads
     // (constant address space: straight into SGPRs, no v_readfirstlane) and written once by lane 0 at the end.
@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_ker
     if (gl == 0 && status_or) atomicOr(p.status, status_or);
 #ifdef UAVENV_STAMPS
     if (p.stamps != nullptr && (threadIdx.x & 63u) == 0) {
-        unsigned long long* q = p.stamps + ((size_t)blockIdx.x * (kBlockThreads / 64) + threadIdx.x / 64) * 8;
+        unsigned long long* q = p.stamps + ((size_t)blockIdx.x * kWaves + threadIdx.x / 64) * 8;
         q[0] = st_t0; q[1] = __builtin_amdgcn_s_memtime(); q[2] = st_r0; q[3] = __builtin_amdgcn_s_memrealtime();
         q[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
         q[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));     // HW_REG_XCC_ID
@@ -1154,12 +1154,12 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_step_ker
 // slots of a replay ring), so the result is bit-identical to K single-step launches.
 // ---------------------------------------------------------------------------------------------
 template <int G, bool kLean>
-__global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_rollout_kernel(const Consts* cptr, Ptrs p, StepArgs a,
+__global__ __launch_bounds__(kSmallBlockThreads, (G == 64 ? 4 : 2)) void uav_rollout_kernel(const Consts* cptr, Ptrs p, StepArgs a,
                                                                                      int32_t num_steps) {
     UAV_CONSTS(cptr);
     const int gl = group_lane<G>();
     const uint32_t grp = threadIdx.x / G;
-    const uint32_t env = blockIdx.x * (kBlockThreads / G) + uni<G>((int)grp);
+    const uint32_t env = blockIdx.x * (kSmallBlockThreads / G) + uni<G>((int)grp);
     const uint32_t idx = env * G + gl;
     const bool in_batch = env < (uint32_t)a.num_envs;
     Sensor s;
@@ -1199,12 +1199,12 @@ __global__ __launch_bounds__(kBlockThreads, (G == 64 ? 4 : 2)) void uav_rollout_
 // noise dump: the tapes the NEXT step / NEXT reset would draw (parity harness for Philox mode)
 // ---------------------------------------------------------------------------------------------
 template <int G>
-__global__ __launch_bounds__(kBlockThreads) void uav_dump_noise_kernel(const Consts* cptr, Ptrs p, float* step_tape,
+__global__ __launch_bounds__(kSmallBlockThreads) void uav_dump_noise_kernel(const Consts* cptr, Ptrs p, float* step_tape,
                                                                        float* reset_tape, int32_t num_envs) {
     constexpr bool kLean = false;
     UAV_CONSTS(cptr);
     const int gl = group_lane<G>();
-    const uint32_t env = blockIdx.x * (kBlockThreads / G) + threadIdx.x / G;
+    const uint32_t env = blockIdx.x * (kSmallBlockThreads / G) + threadIdx.x / G;
     if (env >= (uint32_t)num_envs) return;
     UavEnvRecord r = p.rec[env];
     if (step_tape) {
@@ -1239,11 +1239,11 @@ __global__ __launch_bounds__(kBlockThreads) void uav_dump_noise_kernel(const Con
 // ---------------------------------------------------------------------------------------------
 constexpr int kFsMaxPerLane = 40;      // 64 lanes x 40 floats = 2560 floats per row (k*D <= 2560)
 
-__global__ __launch_bounds__(kBlockThreads) void uav_frame_stack_kernel(float* stacked, const float* obs, const uint8_t* done,
+__global__ __launch_bounds__(kSmallBlockThreads) void uav_frame_stack_kernel(float* stacked, const float* obs, const uint8_t* done,
                                                                       const float* terminal_obs, float* terminal_stacked,
                                                                       int32_t num_envs, int32_t k, int32_t D) {
     const int lane = threadIdx.x & 63;
-    const int env = blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6);
+    const int env = blockIdx.x * (kSmallBlockThreads / 64) + (threadIdx.x >> 6);
     if (env >= num_envs) return;
     const int row = k * D, keep = row - D;
     float* s = stacked + (size_t)env * row;
@@ -1276,7 +1276,7 @@ __global__ __launch_bounds__(kBlockThreads) void uav_frame_stack_kernel(float* s
 hipError_t launch_frame_stack(float* stacked, const float* obs, const uint8_t* done, const float* terminal_obs,
                               float* terminal_stacked, int32_t num_envs, int32_t k, int32_t D, hipStream_t s) {
     if (k < 1 || D < 1 || (long long)k * D > 64LL * kFsMaxPerLane) return hipErrorInvalidValue;
-    dim3 block(kBlockThreads), grid((unsigned)((num_envs + kBlockThreads / 64 - 1) / (kBlockThreads / 64)));
+    dim3 block(kSmallBlockThreads), grid((unsigned)((num_envs + kSmallBlockThreads / 64 - 1) / (kSmallBlockThreads / 64)));
     uav_frame_stack_kernel<<<grid, block, 0, s>>>(stacked, obs, done, terminal_obs, terminal_stacked, num_envs, k, D);
     return hipGetLastError();
 }
@@ -1301,32 +1301,47 @@ static inline size_t lds_bytes(int, const Consts&) { return UAV_LDS_PAD; }     /
 
 hipError_t launch_init(int Gw, int padded_envs, const Consts& c, const Consts* dc, const Ptrs& p, uint32_t env_index_base,
                        int32_t grid_w, int32_t grid_h, int32_t n, float start_x, float start_y, hipStream_t s) {
-    dim3 block(kBlockThreads), grid((unsigned)(padded_envs / (kBlockThreads / Gw)));
+    dim3 block(kSmallBlockThreads), grid((unsigned)(padded_envs / (kSmallBlockThreads / Gw)));
     UAV_DISPATCH_G(Gw, (uav_init_kernel<G><<<grid, block, 0, s>>>(dc, p, env_index_base, grid_w, grid_h, n, start_x, start_y)));
     return hipGetLastError();
 }
 hipError_t launch_reset(int Gw, int padded_envs, const Consts& c, const Consts* dc, const Ptrs& p, const ResetArgs& a, hipStream_t s) {
-    dim3 block(kBlockThreads), grid((unsigned)(padded_envs / (kBlockThreads / Gw)));
+    dim3 block(kSmallBlockThreads), grid((unsigned)(padded_envs / (kSmallBlockThreads / Gw)));
     UAV_DISPATCH_G(Gw, (uav_reset_kernel<G><<<grid, block, lds_bytes(Gw, c), s>>>(dc, p, a)));
     return hipGetLastError();
 }
+bool step_uses_big_workgroups(int Gw, int padded_envs) { return (long)padded_envs * Gw / 64 >= 16L * 256L; }
+
 hipError_t launch_step(int Gw, int padded_envs, const Consts& c, const Consts* dc, const Ptrs& p, const StepArgs& a, hipStream_t s) {
-    dim3 block(kBlockThreads), grid((unsigned)(padded_envs / (kBlockThreads / Gw)));
+    // 16-wave workgroups (one per CU, collect steps dealt over its SIMDs) once every CU gets at least that many waves;
+    // smaller batches use 4-wave workgroups so that they still spread over all CUs
+    const long waves = (long)padded_envs * Gw / 64;
+    const bool big = step_uses_big_workgroups(Gw, padded_envs);
+    const int wg_waves = big ? kBlockThreads / 64 : kSmallBlockThreads / 64;
+    dim3 block(wg_waves * 64), grid((unsigned)(waves / wg_waves));
     const uint64_t be = ((uint64_t)(uint32_t)a.balance << 32) | (uint64_t)(uint32_t)a.num_envs;
-    if (lean_ok(c, p, a)) { UAV_DISPATCH_G(Gw, (uav_step_kernel<G, true><<<grid, block, lds_bytes(Gw, c), s>>>(dc, p.sensor_base, p.lanes, p.rec, a.hint_in, a.actions, be, p, a))); }
-    else { UAV_DISPATCH_G(Gw, (uav_step_kernel<G, false><<<grid, block, lds_bytes(Gw, c), s>>>(dc, p.sensor_base, p.lanes, p.rec, a.hint_in, a.actions, be, p, a))); }
+#define UAV_STEP_LAUNCH(LEAN, WV) uav_step_kernel<G, LEAN, WV><<<grid, block, lds_bytes(Gw, c), s>>>( \
+        dc, p.sensor_base, p.lanes, p.rec, a.hint_in, a.actions, be, p, a)
+    if (lean_ok(c, p, a)) {
+        if (big) { UAV_DISPATCH_G(Gw, (UAV_STEP_LAUNCH(true, kBlockThreads / 64))); }
+        else { UAV_DISPATCH_G(Gw, (UAV_STEP_LAUNCH(true, kSmallBlockThreads / 64))); }
+    } else {
+        if (big) { UAV_DISPATCH_G(Gw, (UAV_STEP_LAUNCH(false, kBlockThreads / 64))); }
+        else { UAV_DISPATCH_G(Gw, (UAV_STEP_LAUNCH(false, kSmallBlockThreads / 64))); }
+    }
+#undef UAV_STEP_LAUNCH
     return hipGetLastError();
 }
 hipError_t launch_rollout(int Gw, int padded_envs, const Consts& c, const Consts* dc, const Ptrs& p, const StepArgs& a,
                           int32_t num_steps, hipStream_t s) {
-    dim3 block(kBlockThreads), grid((unsigned)(padded_envs / (kBlockThreads / Gw)));
+    dim3 block(kSmallBlockThreads), grid((unsigned)(padded_envs / (kSmallBlockThreads / Gw)));
     if (lean_ok(c, p, a)) { UAV_DISPATCH_G(Gw, (uav_rollout_kernel<G, true><<<grid, block, lds_bytes(Gw, c), s>>>(dc, p, a, num_steps))); }
     else { UAV_DISPATCH_G(Gw, (uav_rollout_kernel<G, false><<<grid, block, lds_bytes(Gw, c), s>>>(dc, p, a, num_steps))); }
     return hipGetLastError();
 }
 hipError_t launch_dump_noise(int Gw, int padded_envs, const Consts& c, const Consts* dc, const Ptrs& p, float* step_tape,
                              float* reset_tape, int32_t num_envs, hipStream_t s) {
-    dim3 block(kBlockThreads), grid((unsigned)(padded_envs / (kBlockThreads / Gw)));
+    dim3 block(kSmallBlockThreads), grid((unsigned)(padded_envs / (kSmallBlockThreads / Gw)));
     UAV_DISPATCH_G(Gw, (uav_dump_noise_kernel<G><<<grid, block, 0, s>>>(dc, p, step_tape, reset_tape, num_envs)));
     return hipGetLastError();
 }
