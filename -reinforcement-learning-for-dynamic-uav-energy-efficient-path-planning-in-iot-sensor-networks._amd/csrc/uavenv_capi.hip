@@ -197,6 +197,7 @@ extern "C" int uavenv_create(const UavEnvConfig* cfg, int32_t num_envs, uint32_t
     hipError_t st = hipSetDevice(device);
     if (st != hipSuccess) return bail(UAVENV_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(st));
     const size_t P = (size_t)e->padded_envs, S = P * (size_t)e->G;
+    if (S * 8 >= ((size_t)1 << 32)) { delete e; return fail(nullptr, UAVENV_E_INVALID, "too many environments for one handle (state rows must stay below 4 GiB): shard them"); }
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t off = 0;
     size_t o_sens = off; off += al(S * kSensorBytesPerLane);      // pos_x | pos_y | buffer | gen | tx | lost | avg | flags

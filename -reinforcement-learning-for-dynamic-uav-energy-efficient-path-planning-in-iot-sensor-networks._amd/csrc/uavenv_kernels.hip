@@ -341,19 +341,24 @@ struct SensorBase { char* sensor_base; uint64_t lanes; };      // the two fields
 template <typename T, typename P> __device__ __forceinline__ T* sensor_array(const P& p, uint64_t off) {
     return reinterpret_cast<T*>(p.sensor_base + off * p.lanes);
 }
+// Element `idx` of a state array: uniform base (SGPRs) + a 32-bit byte offset, so the access uses the scalar-base
+// addressing mode and needs no 64-bit per-lane address (uavenv_create refuses batches whose rows pass 4 GiB).
+template <typename T, typename P> __device__ __forceinline__ T& sensor_at(const P& p, uint64_t off, uint32_t idx) {
+    return *reinterpret_cast<T*>(p.sensor_base + off * p.lanes + (uint32_t)(idx * (uint32_t)sizeof(T)));
+}
 template <int G, typename P> __device__ __forceinline__ void load_sensor(const P& p, uint32_t idx, Sensor& s) {
-    s.sx = sensor_array<float>(p, kOffPosX)[idx]; s.sy = sensor_array<float>(p, kOffPosY)[idx];
-    s.b = sensor_array<double>(p, kOffBuffer)[idx]; s.gen = sensor_array<double>(p, kOffGen)[idx];
-    s.tx = sensor_array<double>(p, kOffTx)[idx]; s.lost = sensor_array<double>(p, kOffLost)[idx];
-    s.avg = sensor_array<double>(p, kOffAvg)[idx];
-    s.flags = sensor_array<uint32_t>(p, kOffFlags)[idx];
+    s.sx = sensor_at<float>(p, kOffPosX, idx); s.sy = sensor_at<float>(p, kOffPosY, idx);
+    s.b = sensor_at<double>(p, kOffBuffer, idx); s.gen = sensor_at<double>(p, kOffGen, idx);
+    s.tx = sensor_at<double>(p, kOffTx, idx); s.lost = sensor_at<double>(p, kOffLost, idx);
+    s.avg = sensor_at<double>(p, kOffAvg, idx);
+    s.flags = sensor_at<uint32_t>(p, kOffFlags, idx);
 }
 template <int G, typename P> __device__ __forceinline__ void store_sensor(const P& p, uint32_t idx, const Sensor& s, bool with_pos) {
-    if (with_pos) { sensor_array<float>(p, kOffPosX)[idx] = s.sx; sensor_array<float>(p, kOffPosY)[idx] = s.sy; }
-    sensor_array<double>(p, kOffBuffer)[idx] = s.b; sensor_array<double>(p, kOffGen)[idx] = s.gen;
-    sensor_array<double>(p, kOffTx)[idx] = s.tx; sensor_array<double>(p, kOffLost)[idx] = s.lost;
-    sensor_array<double>(p, kOffAvg)[idx] = s.avg;
-    sensor_array<uint32_t>(p, kOffFlags)[idx] = s.flags;
+    if (with_pos) { sensor_at<float>(p, kOffPosX, idx) = s.sx; sensor_at<float>(p, kOffPosY, idx) = s.sy; }
+    sensor_at<double>(p, kOffBuffer, idx) = s.b; sensor_at<double>(p, kOffGen, idx) = s.gen;
+    sensor_at<double>(p, kOffTx, idx) = s.tx; sensor_at<double>(p, kOffLost, idx) = s.lost;
+    sensor_at<double>(p, kOffAvg, idx) = s.avg;
+    sensor_at<uint32_t>(p, kOffFlags, idx) = s.flags;
 }
 
 // dqn.py:406-412 distance to the nearest sensor that still has data (float32 norm), 0 if none
