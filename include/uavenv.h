@@ -191,7 +191,11 @@ int uavenv_reset(UavEnv* env, const uint8_t* mask_dev, float* obs_out_dev, void*
  *   reward_out_dev    double [E]          nullable
  *   reward32_out_dev  float [E]           nullable (what SB3's VecEnv hands the agent)
  *   done_out_dev      uint8 [E]           truncated flag (`terminated` is always False: uav_env.py:471)
- *   terminal_obs_dev  float [E][obs_dim]  nullable; rows written only where done (SB3 "terminal_observation") */
+ *   terminal_obs_dev  float [E][obs_dim]  nullable; rows written only where done (SB3 "terminal_observation")
+ * The action array must stay unmodified until the launch has finished (it is read through the scalar cache).
+ * Scheduling note: the wavefronts of a workgroup pick their environments collect-actions-first so that the
+ * expensive collect steps spread over a CU's SIMDs; results do not depend on it (UAVENV_NO_BALANCE=1 in the
+ * process environment at uavenv_create time keeps the plain mapping, for A/B timing). */
 int uavenv_step(UavEnv* env, const int32_t* actions_dev, float* obs_out_dev, double* reward_out_dev,
                 float* reward32_out_dev, uint8_t* done_out_dev, float* terminal_obs_dev, void* stream);
 
