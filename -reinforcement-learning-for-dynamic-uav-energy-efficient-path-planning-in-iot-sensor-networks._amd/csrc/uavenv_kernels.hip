@@ -353,6 +353,21 @@ template <int G, typename P> __device__ __forceinline__ void load_sensor(const P
     s.avg = sensor_at<double>(p, kOffAvg, idx);
     s.flags = sensor_at<uint32_t>(p, kOffFlags, idx);
 }
+// Write back what the step can have changed: nothing for lanes beyond the environment's sensor count (`live` false:
+// their state never changes), `tx` only if some lane of the wave collected or reset (compared with the loaded value),
+// `lost` only if some buffer overflowed or reset.  Cuts the write traffic by about a third.
+template <int G, typename P> __device__ __forceinline__ void store_sensor(const P& p, uint32_t idx, const Sensor& s, bool with_pos,
+                                                                          bool live, double tx0, double lost0) {
+    if (with_pos && live) { sensor_at<float>(p, kOffPosX, idx) = s.sx; sensor_at<float>(p, kOffPosY, idx) = s.sy; }
+    if (live) {
+        sensor_at<double>(p, kOffBuffer, idx) = s.b; sensor_at<double>(p, kOffGen, idx) = s.gen;
+        sensor_at<double>(p, kOffAvg, idx) = s.avg;
+        sensor_at<uint32_t>(p, kOffFlags, idx) = s.flags;
+    }
+    if (__any(live & (s.tx != tx0)) && live) sensor_at<double>(p, kOffTx, idx) = s.tx;
+    if (__any(live & (s.lost != lost0)) && live) sensor_at<double>(p, kOffLost, idx) = s.lost;
+}
+// unconditional form (initialisation, reset kernel)
 template <int G, typename P> __device__ __forceinline__ void store_sensor(const P& p, uint32_t idx, const Sensor& s, bool with_pos) {
     if (with_pos) { sensor_at<float>(p, kOffPosX, idx) = s.sx; sensor_at<float>(p, kOffPosY, idx) = s.sy; }
     sensor_at<double>(p, kOffBuffer, idx) = s.b; sensor_at<double>(p, kOffGen, idx) = s.gen;
@@ -700,7 +715,7 @@ __device__ __forceinline__ uint32_t hint_tag(uint32_t episode, uint32_t step) { 
 
 template <int G, bool kLean, bool kRegs = false, typename RecPtr = UavEnvRecord*, typename P = Ptrs, typename A = StepArgs>
 __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32_t env, bool in_batch,
-                                          RecPtr rec, UavEnvRecord* rec_out, Sensor& s, bool& wrote_pos, uint32_t& status_or,
+                                          RecPtr rec, UavEnvRecord* rec_out, Sensor& s, bool& wrote_pos, bool& live, uint32_t& status_or,
                                           int& action_out, uint32_t hint_word = 0u) {
     const int gl = group_lane<G>();
     UAV_PHASE(0);
@@ -1050,6 +1065,7 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
         wrote_pos |= draw_layout && do_reset;
     }
     if (kRegs) *rec_out = r; else if (gl == 0) *rec_out = r;
+    live |= gl < r.num_sensors;
     status_or |= r.status;
     // The next launch's word: the action this environment draws next (after a possible auto-reset: exact), computed
     // here, late, on the scalar unit -- off the critical path of the NEXT launch's wave start (G = 64 only).
@@ -1125,7 +1141,8 @@ __global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kerne
     const bool in_batch = env < (uint32_t)num_envs;
     Sensor s;
     load_sensor<G>(sb, idx, s);
-    bool wrote_pos = false;
+    const double tx0 = s.tx, lost0 = s.lost;
+    bool wrote_pos = false, live = false;
     uint32_t status_or = 0u;
     int action = 0;
     uint32_t hint_word = 0u;
@@ -1136,10 +1153,10 @@ __global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kerne
     if (G == 64) {
         typedef const __attribute__((address_space(4))) UavEnvRecord* ScalarRec;
         step_once<G, kLean, false, ScalarRec>(c, p, a, env, in_batch, (ScalarRec)(rec_base + env), rec_base + env, s, wrote_pos,
-                                              status_or, action, hint_word);
+                                              live, status_or, action, hint_word);
     } else
-        step_once<G, kLean>(c, p, a, env, in_batch, rec_base + env, rec_base + env, s, wrote_pos, status_or, action, hint_word);
-    store_sensor<G>(sb, idx, s, wrote_pos);
+        step_once<G, kLean>(c, p, a, env, in_batch, rec_base + env, rec_base + env, s, wrote_pos, live, status_or, action, hint_word);
+    store_sensor<G>(sb, idx, s, wrote_pos, live, tx0, lost0);
     if (gl == 0 && status_or) atomicOr(p.status, status_or);
 #ifdef UAVENV_STAMPS
     if (p.stamps != nullptr && (threadIdx.x & 63u) == 0) {
@@ -1169,8 +1186,9 @@ __global__ __launch_bounds__(kSmallBlockThreads, (G == 64 ? 4 : 2)) void uav_rol
     const bool in_batch = env < (uint32_t)a.num_envs;
     Sensor s;
     load_sensor<G>(p, idx, s);
+    const double tx0 = s.tx, lost0 = s.lost;
     UavEnvRecord rr = p.rec[env];
-    bool wrote_pos = false;
+    bool wrote_pos = false, live = false;
     uint32_t status_or = 0u;
     const size_t E = (size_t)a.num_envs;
     for (int k = 0; k < num_steps; k++) {
@@ -1190,12 +1208,12 @@ __global__ __launch_bounds__(kSmallBlockThreads, (G == 64 ? 4 : 2)) void uav_rol
         const Consts* cp = cptr;
         asm volatile("" : "+s"(cp));
         CRef ck = *(const __attribute__((address_space(4))) Consts*)(cp);
-        step_once<G, kLean, true>(ck, p, ak, env, in_batch, &rr, &rr, s, wrote_pos, status_or, action);
+        step_once<G, kLean, true>(ck, p, ak, env, in_batch, &rr, &rr, s, wrote_pos, live, status_or, action);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    store_sensor<G>(p, idx, s, wrote_pos);
+    store_sensor<G>(p, idx, s, wrote_pos, live, tx0, lost0);
     if (gl == 0) p.rec[env] = rr;
     if (gl == 0 && status_or) atomicOr(p.status, status_or);
 }
