@@ -90,11 +90,11 @@ import sys, hashlib
 sys.path.insert(0, %r)
 import torch, uavenv_amd as U
 h = hashlib.sha256()
-for E, n in ((37, 50), (256, 50), (100, 20), (64, 10)):
+for E, n in ((37, 50), (256, 50), (100, 20), (64, 10), (4096 + 37, 50), (8192 + 5, 20), (16384 + 3, 10)):   # the last three: 16-wave workgroups
     env = U.BatchedUAVEnv(E, num_sensors=n, seed=5, max_steps=30)
     env.reset()
     g = torch.Generator(device="cpu"); g.manual_seed(E)
-    for s in range(70):
+    for s in range(70 if E < 1000 else 24):
         if s %% 3 == 2:
             env.step_random()
         else:

@@ -145,6 +145,10 @@ KEYED_CASES = [
     ("domain_rand", 72, dict(num_sensors=20, pad_sensors=50, duty_cycle=50.0, max_steps=60,
                              grid_choices=[(100, 100), (200, 200), (300, 300)]), 250, 1 | 2 | 4 | 8),
     ("shaping_only", 40, dict(num_sensors=10, duty_cycle=100.0, grid_size=(100, 100), max_steps=55), 150, 4 | 8),
+    # batches big enough for the 16-wave workgroups with SIMD load balancing, for every lane-group width
+    ("n50_big_workgroups", 4096 + 21, dict(num_sensors=50, max_steps=9, duty_cycle=60.0, grid_size=(150, 150)), 14, 0),
+    ("n20_big_workgroups", 8192 + 5, dict(num_sensors=20, max_steps=7, duty_cycle=80.0, grid_size=(120, 120)), 10, 0),
+    ("n10_big_workgroups", 16384 + 3, dict(num_sensors=10, max_steps=6, duty_cycle=100.0, grid_size=(90, 90)), 8, 0),
 ]
 
 
