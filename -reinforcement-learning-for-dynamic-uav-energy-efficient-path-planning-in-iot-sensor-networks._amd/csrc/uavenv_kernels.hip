@@ -716,8 +716,10 @@ __device__ __forceinline__ uint32_t hint_tag(uint32_t episode, uint32_t step) { 
 template <int G, bool kLean, bool kRegs = false, typename RecPtr = UavEnvRecord*, typename P = Ptrs, typename A = StepArgs>
 __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32_t env, bool in_batch,
                                           RecPtr rec, UavEnvRecord* rec_out, Sensor& s, bool& wrote_pos, bool& live, uint32_t& status_or,
-                                          int& action_out, uint32_t hint_word = 0u) {
+                                          int& action_out, uint32_t hint_word = 0u, size_t row_offset = 0) {
     const int gl = group_lane<G>();
+    // outputs of fused rollouts are [K][E][...] blocks: row = k * E + env (k = 0 for the single-step kernel)
+    const size_t out = row_offset + env;
     UAV_PHASE(0);
     Env e = load_env<G>(rec);
     const int n = e.n;
@@ -729,8 +731,8 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
     if (UAV_POLICY(a) >= UAVENV_POLICY_NEAREST) {                    // heuristic baseline evaluated on device
         const float zP = draw_policy_noise<G, kLean>(c, p, e.env_index, e.episode, env, in_batch, step);
         action = uni<G>(policy_action<G>(c, s, e, act, a.policy, zP));
-        if (a.actions_out != nullptr && in_batch && gl == 0) a.actions_out[env] = action;
-    } else if (UAV_POLICY(a) == UAVENV_POLICY_ACTIONS) action = uni<G>(in_batch ? a.actions[env] : 0);
+        if (a.actions_out != nullptr && in_batch && gl == 0) a.actions_out[out] = action;
+    } else if (UAV_POLICY(a) == UAVENV_POLICY_ACTIONS) action = uni<G>(in_batch ? a.actions[out] : 0);
     else {                                                       // uniform-random policy (Philox call 3)
 #ifdef UAV_ABL_CHEAPACTION   // timing-only ablation build: no Philox on the scalar unit for the action / the hint
         action = (int)((e.env_index * 7u + step * 3u + e.episode) % 5u);
@@ -738,7 +740,7 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
         if (G == 64 && (hint_word & ~7u) == hint_tag(e.episode, step)) action = (int)(hint_word & 7u);   // drawn last launch
         else action = (int)(((uint64_t)noise_words(c.seed, e.env_index, e.episode, step, 0u, 3).w0 * 5u) >> 32);
 #endif
-        if (a.actions_out != nullptr && in_batch && gl == 0) a.actions_out[env] = action;
+        if (a.actions_out != nullptr && in_batch && gl == 0) a.actions_out[out] = action;
     }
     const bool is_c = action == 4;
     const bool is_m = (action >= 0) & (action <= 3);
@@ -972,8 +974,8 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
     {
         float* dst = nullptr;
         if (in_batch) {
-            if (do_reset) dst = a.term_obs ? a.term_obs + env * (size_t)c.obs_dim : nullptr;
-            else dst = a.obs ? a.obs + env * (size_t)c.obs_dim : nullptr;
+            if (do_reset) dst = a.term_obs ? a.term_obs + out * (size_t)c.obs_dim : nullptr;
+            else dst = a.obs ? a.obs + out * (size_t)c.obs_dim : nullptr;
         }
         if (a.term_pool != nullptr) {          // kernel-uniform: terminal rows go to a compact pool instead
             int row = -1;
@@ -983,7 +985,7 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
                 t = gshfl<G>(t, 0);
                 if (do_reset & in_batch) { row = (int)t; dst = a.term_pool + (size_t)t * (size_t)c.obs_dim; }
             }
-            if (in_batch && gl == 0 && a.term_index != nullptr) a.term_index[env] = row;
+            if (in_batch && gl == 0 && a.term_index != nullptr) a.term_index[out] = row;
             term_row = row;
         }
         observe<G, kLean>(c, s, n, e.gw, e.gh, e.inv_w, e.inv_h, e.ux, e.uy, e.battery, act, true, det, z.zD, z.zE, dst);   // :488
@@ -1025,10 +1027,10 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
     r.episode_return += reward;
 
     if (in_batch && gl == 0) {
-        if (a.reward) a.reward[env] = reward;
-        if (a.reward32) a.reward32[env] = (float)reward;
-        if (a.done) a.done[env] = truncated ? 1 : 0;
-        if (a.aux) reinterpret_cast<float4*>(a.aux)[env] = make_float4((float)action, (float)reward, truncated ? 1.0f : 0.0f,
+        if (a.reward) a.reward[out] = reward;
+        if (a.reward32) a.reward32[out] = (float)reward;
+        if (a.done) a.done[out] = truncated ? 1 : 0;
+        if (a.aux) reinterpret_cast<float4*>(a.aux)[out] = make_float4((float)action, (float)reward, truncated ? 1.0f : 0.0f,
                                                                     (float)term_row);
     }
 
@@ -1056,7 +1058,7 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
         if (UAV_FLAGS(c) & UAVENV_FLAG_FAR_START) far_start<G>(c, s, r, act, do_reset);
         if (do_reset) { r.uav_x = r.start_x; r.uav_y = r.start_y; }
         double det0 = rssi_deterministic(c, r.uav_x, r.uav_y, s.sx, s.sy);
-        float* dst = (in_batch && a.obs) ? a.obs + env * (size_t)c.obs_dim : nullptr;
+        float* dst = (in_batch && a.obs) ? a.obs + out * (size_t)c.obs_dim : nullptr;
         observe<G, kLean>(c, s, r.num_sensors, r.grid_w, r.grid_h, r.inv_grid_w, r.inv_grid_h, r.uav_x, r.uav_y, r.battery, act, do_reset, det0, zD, zE, dst);
         if (UAV_FLAGS(c) & UAVENV_FLAG_PROX_SHAPING) {
             double d0 = dist_nearest_with_data<G>(s, act, r.uav_x, r.uav_y);
@@ -1176,8 +1178,14 @@ __global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kerne
 // slots of a replay ring), so the result is bit-identical to K single-step launches.
 // ---------------------------------------------------------------------------------------------
 template <int G, bool kLean>
-__global__ __launch_bounds__(kSmallBlockThreads, (G == 64 ? 4 : 2)) void uav_rollout_kernel(const Consts* cptr, Ptrs p, StepArgs a,
+__global__ __launch_bounds__(kSmallBlockThreads, (G == 64 ? 4 : 2)) void uav_rollout_kernel(const Consts* cptr, Ptrs p_in, StepArgs a_in,
                                                                                      int32_t num_steps) {
+    // as in the step kernel, the argument structs are read in place from the kernarg segment (constant address space)
+    struct Kernargs { const Consts* cptr; Ptrs p; StepArgs a; int32_t num_steps; };
+    typedef const __attribute__((address_space(4))) unsigned char* KA;
+    KA ka0 = (KA)__builtin_amdgcn_kernarg_segment_ptr();
+    const __attribute__((address_space(4))) Ptrs& p = *(const __attribute__((address_space(4))) Ptrs*)(ka0 + offsetof(Kernargs, p));
+    const __attribute__((address_space(4))) StepArgs& a = *(const __attribute__((address_space(4))) StepArgs*)(ka0 + offsetof(Kernargs, a));
     UAV_CONSTS(cptr);
     const int gl = group_lane<G>();
     const uint32_t grp = threadIdx.x / G;
@@ -1192,26 +1200,19 @@ __global__ __launch_bounds__(kSmallBlockThreads, (G == 64 ? 4 : 2)) void uav_rol
     uint32_t status_or = 0u;
     const size_t E = (size_t)a.num_envs;
     for (int k = 0; k < num_steps; k++) {
-        StepArgs ak = a;
-        if (a.actions) ak.actions = a.actions + (size_t)k * E;
-        if (a.actions_out) ak.actions_out = a.actions_out + (size_t)k * E;
-        if (a.obs) ak.obs = a.obs + (size_t)k * E * (size_t)c.obs_dim;
-        if (a.term_obs) ak.term_obs = a.term_obs + (size_t)k * E * (size_t)c.obs_dim;
-        if (a.reward) ak.reward = a.reward + (size_t)k * E;
-        if (a.reward32) ak.reward32 = a.reward32 + (size_t)k * E;
-        if (a.done) ak.done = a.done + (size_t)k * E;
-        if (a.term_index) ak.term_index = a.term_index + (size_t)k * E;
-        if (a.aux) ak.aux = a.aux + (size_t)k * E * 4;
         int action = 0;
         // Launder the constants pointer every iteration: otherwise LICM hoists all ~90 invariant scalar loads
         // out of the loop and the SGPR file spills into VGPR lanes (and those into scratch).
         const Consts* cp = cptr;
         asm volatile("" : "+s"(cp));
         CRef ck = *(const __attribute__((address_space(4))) Consts*)(cp);
-        step_once<G, kLean, true>(ck, p, ak, env, in_batch, &rr, &rr, s, wrote_pos, live, status_or, action);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        KA ka = ka0;                              // same for the argument structs
+        asm volatile("" : "+s"(ka));
+        const __attribute__((address_space(4))) Ptrs& pk = *(const __attribute__((address_space(4))) Ptrs*)(ka + offsetof(Kernargs, p));
+        const __attribute__((address_space(4))) StepArgs& ak = *(const __attribute__((address_space(4))) StepArgs*)(ka + offsetof(Kernargs, a));
+        // every step writes block k of the [K][E][...] outputs: the row offset k * E goes to step_once, the argument
+        // structs stay untouched (no per-step copies of nine pointers competing for SGPRs)
+        step_once<G, kLean, true>(ck, pk, ak, env, in_batch, &rr, &rr, s, wrote_pos, live, status_or, action, 0u, (size_t)k * E);
     }
     store_sensor<G>(p, idx, s, wrote_pos, live, tx0, lost0);
     if (gl == 0) p.rec[env] = rr;
