@@ -453,7 +453,7 @@ __device__ __forceinline__ void observe(CRef c, Sensor& s, int n, int gw, int gh
 // Noise for one step of one lane: Philox, or the injected tape (parity testing).  zC (the range check of
 // collect_data) is only needed by Capture-Effect winners, so its Box-Muller is deferred: the two Philox
 // words are kept and converted on demand (finish_zc).
-struct StepNoise { float zA, zB, u, zC, zD, zE; uint32_t c2, c3; bool zc_ready; };
+struct StepNoise { float zA, zB, u, zC, zD, zE; uint32_t c2, c3; bool zc_ready; uint32_t w3; bool have_w3; };
 
 // zP: the shadowing sample of the is_in_range() call a heuristic policy makes before the step (Philox call 5)
 template <int G, bool kLean, typename P>
@@ -530,7 +530,7 @@ template <int G, bool kLean, typename P>
 __device__ __forceinline__ void draw_step_noise(CRef c, const P& p, uint32_t env_index, uint32_t episode,
                                                 size_t env, bool in_batch, uint32_t step, bool need_collect, StepNoise& z) {
     const int gl = group_lane<G>();
-    z.c2 = z.c3 = 0u; z.zc_ready = true;
+    z.c2 = z.c3 = 0u; z.zc_ready = true; z.w3 = 0u; z.have_w3 = false;
     if (UAV_TAPE(p.step_tape) != nullptr) {                      // kernel-uniform
         z.zA = z.zB = z.zC = z.zD = z.zE = 0.f; z.u = 1.f;
         if (in_batch) {                                // the tape has no rows for the padding environments
@@ -543,6 +543,7 @@ __device__ __forceinline__ void draw_step_noise(CRef c, const P& p, uint32_t env
     Words4 w = noise_words(c.seed, env_index, episode, step, (uint32_t)gl, 0);
     normal_pair(w.w0, w.w1, z.zD, z.zE);
     z.u = u24(w.w2);
+    z.w3 = w.w3; z.have_w3 = true;             // lane 0's spare word is the uniform-random policy's NEXT action
     z.zA = z.zB = z.zC = 0.f;
 #ifdef UAV_ABL_NOCNOISE      // timing-only ablation build (tools/ablate.py)
     if (need_collect) { z.zA = z.zE; z.zB = z.zD; z.c2 = w.w2; z.c3 = w.w3; z.zc_ready = false; }
@@ -563,7 +564,8 @@ __device__ __forceinline__ void finish_zc(StepNoise& z) {   // call under wave-u
 // registers in `s`, the record in `r`, and returns (zD, zE) of the reset observation.
 template <int G, bool kLean, typename P>
 __device__ __forceinline__ void reset_group(CRef c, const P& p, Sensor& s, UavEnvRecord& r, size_t env,
-                                            bool in_batch, bool rs, bool draw_layout, float& zD, float& zE) {
+                                            bool in_batch, bool rs, bool draw_layout, float& zD, float& zE,
+                                            uint32_t& w3, bool& have_w3) {
     const int gl = group_lane<G>();
     if (!rs) return;                                   // group-uniform; no cross-lane ops skipped below
     r.episode += 1u;
@@ -588,6 +590,7 @@ __device__ __forceinline__ void reset_group(CRef c, const P& p, Sensor& s, UavEn
     } else {
         Words4 v = noise_words(c.seed, r.env_index, ep, 0u, (uint32_t)gl, 0);
         normal_pair(v.w0, v.w1, zD, zE);
+        w3 = v.w3; have_w3 = true;
     }
     if (draw_layout) {                                                             // uav_env.py:366-374 / dqn.py:342-344
         s.sx = u24(w.w1) * (float)r.grid_w;
@@ -686,7 +689,8 @@ __global__ __launch_bounds__(kSmallBlockThreads) void uav_reset_kernel(const Con
 
     float zD = 0.f, zE = 0.f;
     const bool draw_layout = (UAV_FLAGS(c) & UAVENV_FLAG_RANDOM_LAYOUT) != 0;
-    reset_group<G, kLean>(c, p, s, r, env, in_batch, rs, draw_layout, zD, zE);
+    uint32_t rw3 = 0u; bool have_rw3 = false;
+    reset_group<G, kLean>(c, p, s, r, env, in_batch, rs, draw_layout, zD, zE, rw3, have_rw3);
     if (UAV_FLAGS(c) & UAVENV_FLAG_FAR_START) far_start<G>(c, s, r, act, rs);
     if (rs) { r.uav_x = r.start_x; r.uav_y = r.start_y; }                         // uav.py:256, dqn.py:364-365
     double det = rssi_deterministic(c, r.uav_x, r.uav_y, s.sx, s.sy);
@@ -707,6 +711,10 @@ __global__ __launch_bounds__(kSmallBlockThreads) void uav_reset_kernel(const Con
 // global memory) and the fused rollout kernel (record staged in LDS, sensor state kept in registers
 // across steps).  `rec` may point to global memory or LDS.
 // ---------------------------------------------------------------------------------------------
+// The uniform-random policy's action of step s is word 3 of the Philox call that lane 0 makes ANYWAY for the observation
+// noise of step s-1 (call 0; for s = 1 the call of the reset observation): the policy costs no generator call of its own.
+__device__ __forceinline__ int random_action(uint32_t w3) { return (int)(((uint64_t)w3 * 5u) >> 32); }
+
 // Scheduling / action word the random-policy step leaves for the next launch: bits 0-2 the action of (episode, step),
 // bit 3 "valid", bits 4-19 step, bits 20-31 episode (low bits).  A launch uses the action of a word whose tag matches the
 // record it finds (else it draws the action itself: the word is an optimisation, never a source of truth), and every
@@ -716,7 +724,7 @@ __device__ __forceinline__ uint32_t hint_tag(uint32_t episode, uint32_t step) { 
 template <int G, bool kLean, bool kRegs = false, typename RecPtr = UavEnvRecord*, typename P = Ptrs, typename A = StepArgs>
 __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32_t env, bool in_batch,
                                           RecPtr rec, UavEnvRecord* rec_out, Sensor& s, bool& wrote_pos, bool& live, uint32_t& status_or,
-                                          int& action_out, uint32_t hint_word = 0u, size_t row_offset = 0) {
+                                          int& action_out, uint32_t& next_word, uint32_t hint_word = 0u, size_t row_offset = 0) {
     const int gl = group_lane<G>();
     // outputs of fused rollouts are [K][E][...] blocks: row = k * E + env (k = 0 for the single-step kernel)
     const size_t out = row_offset + env;
@@ -736,9 +744,10 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
     else {                                                       // uniform-random policy (Philox call 3)
 #ifdef UAV_ABL_CHEAPACTION   // timing-only ablation build: no Philox on the scalar unit for the action / the hint
         action = (int)((e.env_index * 7u + step * 3u + e.episode) % 5u);
+        (void)hint_word;
 #else
         if (G == 64 && (hint_word & ~7u) == hint_tag(e.episode, step)) action = (int)(hint_word & 7u);   // drawn last launch
-        else action = (int)(((uint64_t)noise_words(c.seed, e.env_index, e.episode, step, 0u, 3).w0 * 5u) >> 32);
+        else action = random_action(noise_words(c.seed, e.env_index, e.episode, step - 1u, 0u, 0).w3);   // not handed over: draw it
 #endif
         if (a.actions_out != nullptr && in_batch && gl == 0) a.actions_out[out] = action;
     }
@@ -1035,6 +1044,7 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
     }
 
     // ---- SB3 VecEnv auto-reset: episode stats, reset, first observation of the new episode -----------
+    uint32_t reset_w3 = 0u; bool have_reset_w3 = false;
     if (__any(do_reset)) {
         {   // dqn.py:305-331 last_episode_stats (+ Monitor r/l)
             double std_rates;
@@ -1054,7 +1064,7 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
         }
         float zD = 0.f, zE = 0.f;
         const bool draw_layout = (UAV_FLAGS(c) & UAVENV_FLAG_RANDOM_LAYOUT) != 0;
-        reset_group<G, kLean>(c, p, s, r, env, in_batch, do_reset, draw_layout, zD, zE);
+        reset_group<G, kLean>(c, p, s, r, env, in_batch, do_reset, draw_layout, zD, zE, reset_w3, have_reset_w3);
         if (UAV_FLAGS(c) & UAVENV_FLAG_FAR_START) far_start<G>(c, s, r, act, do_reset);
         if (do_reset) { r.uav_x = r.start_x; r.uav_y = r.start_y; }
         double det0 = rssi_deterministic(c, r.uav_x, r.uav_y, s.sx, s.sy);
@@ -1069,16 +1079,23 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
     if (kRegs) *rec_out = r; else if (gl == 0) *rec_out = r;
     live |= gl < r.num_sensors;
     status_or |= r.status;
-    // The next launch's word: the action this environment draws next (after a possible auto-reset: exact), computed
-    // here, late, on the scalar unit -- off the critical path of the NEXT launch's wave start (G = 64 only).
-    if (!kRegs && G == 64 && a.hint_out != nullptr) {
+    // The action this environment draws NEXT (after a possible auto-reset: exact), tagged with its (episode, step): lane
+    // 0's spare word of the observation-noise call made above.  The step kernel leaves it for the next launch (which uses
+    // it for scheduling and, after checking the tag against the record, as the action); the rollout kernel carries it.
+    next_word = 0u;
+    if (G == 64 && UAV_POLICY(a) == UAVENV_POLICY_RANDOM) {
         const uint32_t ns = (uint32_t)(r.current_step + 1);
 #ifdef UAV_ABL_CHEAPACTION
         const uint32_t na = (r.env_index * 7u + ns * 3u + r.episode) % 5u;
 #else
-        const uint32_t na = (uint32_t)(((uint64_t)noise_words(c.seed, r.env_index, r.episode, ns, 0u, 3).w0 * 5u) >> 32);
+        const bool was_reset = __any(do_reset) != 0;                               // wave-uniform (G = 64)
+        const bool have = was_reset ? have_reset_w3 : z.have_w3;
+        uint32_t w3n = (uint32_t)__builtin_amdgcn_readlane((int)(was_reset ? reset_w3 : z.w3), 0);
+        if (!have) w3n = noise_words(c.seed, r.env_index, r.episode, ns - 1u, 0u, 0).w3;   // noise came from a tape: draw it
+        const uint32_t na = (uint32_t)random_action(w3n);
 #endif
-        if (gl == 0) a.hint_out[env] = na | hint_tag(r.episode, ns);
+        next_word = na | hint_tag(r.episode, ns);
+        if (!kRegs && a.hint_out != nullptr && gl == 0) a.hint_out[env] = next_word;
     }
     UAV_PHASE(7);
 
@@ -1147,17 +1164,18 @@ __global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kerne
     bool wrote_pos = false, live = false;
     uint32_t status_or = 0u;
     int action = 0;
+    uint32_t next_word = 0u;
     uint32_t hint_word = 0u;
-    if (G == 64 && kWaves >= 8 && actions == nullptr)
+    if (G == 64 && actions == nullptr)
         hint_word = ((const __attribute__((address_space(4))) uint32_t*)hint_in)[blockIdx.x * kWaves + (uint32_t)unit];
     // G = 64: the record is wave-uniform and nobody else touches it during the launch, so it is read with scalar loads
     // (constant address space: straight into SGPRs, no v_readfirstlane) and written once by lane 0 at the end.
     if (G == 64) {
         typedef const __attribute__((address_space(4))) UavEnvRecord* ScalarRec;
         step_once<G, kLean, false, ScalarRec>(c, p, a, env, in_batch, (ScalarRec)(rec_base + env), rec_base + env, s, wrote_pos,
-                                              live, status_or, action, hint_word);
+                                              live, status_or, action, next_word, hint_word);
     } else
-        step_once<G, kLean>(c, p, a, env, in_batch, rec_base + env, rec_base + env, s, wrote_pos, live, status_or, action, hint_word);
+        step_once<G, kLean>(c, p, a, env, in_batch, rec_base + env, rec_base + env, s, wrote_pos, live, status_or, action, next_word, hint_word);
     store_sensor<G>(sb, idx, s, wrote_pos, live, tx0, lost0);
     if (gl == 0 && status_or) atomicOr(p.status, status_or);
 #ifdef UAVENV_STAMPS
@@ -1199,6 +1217,7 @@ __global__ __launch_bounds__(kSmallBlockThreads, (G == 64 ? 4 : 2)) void uav_rol
     bool wrote_pos = false, live = false;
     uint32_t status_or = 0u;
     const size_t E = (size_t)a.num_envs;
+    uint32_t carried_word = 0u;      // the random policy's next action, handed from step to step (0: draw it)
     for (int k = 0; k < num_steps; k++) {
         int action = 0;
         // Launder the constants pointer every iteration: otherwise LICM hoists all ~90 invariant scalar loads
@@ -1212,7 +1231,7 @@ __global__ __launch_bounds__(kSmallBlockThreads, (G == 64 ? 4 : 2)) void uav_rol
         const __attribute__((address_space(4))) StepArgs& ak = *(const __attribute__((address_space(4))) StepArgs*)(ka + offsetof(Kernargs, a));
         // every step writes block k of the [K][E][...] outputs: the row offset k * E goes to step_once, the argument
         // structs stay untouched (no per-step copies of nine pointers competing for SGPRs)
-        step_once<G, kLean, true>(ck, pk, ak, env, in_batch, &rr, &rr, s, wrote_pos, live, status_or, action, 0u, (size_t)k * E);
+        step_once<G, kLean, true>(ck, pk, ak, env, in_batch, &rr, &rr, s, wrote_pos, live, status_or, action, carried_word, carried_word, (size_t)k * E);
     }
     store_sensor<G>(p, idx, s, wrote_pos, live, tx0, lost0);
     if (gl == 0) p.rec[env] = rr;

@@ -6,11 +6,11 @@
 //     counter = (global env index, episode, step, lane | call << 16).
 //
 //   call 0 (every step; step 0 = the observation built inside reset):
-//            w0,w1 -> (zD, zE) observation ADR sample / in-range sample;  w2 -> lottery uniform u
+//            w0,w1 -> (zD, zE) observation ADR sample / in-range sample;  w2 -> lottery uniform u;
+//            lane 0's w3 -> the uniform-random policy's action of the NEXT step (scaled to 0..4)
 //   call 1 (collect steps only): w0,w1 -> (zA, zB);  w2,w3 -> (zC, unused)
 //   call 2 (reset, step 0):      w0 -> buffer-fill uniform; w1,w2 -> sensor layout x,y;
 //                                lane 0's w3 -> curriculum grid choice
-//   call 3 (lane 0):             w0 -> uniform-random policy action
 //   call 4 (lane field = try):   w0,w1 -> far-start candidate
 //
 // Normals come from a Box-Muller transform written WITHOUT transcendental instructions: only IEEE

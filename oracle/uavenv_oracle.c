@@ -647,7 +647,7 @@ void orc_normal_pair(uint32_t a, uint32_t b, float* z0, float* z1) {
  *   call 0 (every step incl. step 0 = reset observation): w0,w1 -> (zD,zE); w2 -> lottery u
  *   call 1 (collect steps):                               w0,w1 -> (zA,zB); w2,w3 -> (zC,-)
  *   call 2 (reset, step 0): w0 -> u_fill; w1,w2 -> layout x,y; lane 0's w3 -> curriculum grid choice
- *   call 3 (lane 0):        w0 -> random-policy action
+ *   (no call 3: the random policy's action of step s is lane 0's w3 of call 0 at step s-1)
  *   call 4 (lane = try):    w0,w1 -> far-start candidate
  *   call 5 (policy steps):  w0,w1 -> (zP, -) in-range sample drawn by a heuristic policy before the step */
 static void noise_words(uint64_t seed, uint32_t env, uint32_t ep, uint32_t step, uint32_t lane,
@@ -688,10 +688,12 @@ void orc_noise_positions(uint64_t seed, uint32_t env, uint32_t ep, int n, int gw
         py[i] = u24(w[2]) * (float)gh;
     }
 }
+/* uniform-random policy: the action of step s (s >= 1) is word 3 of the call that lane 0 makes for the observation
+ * noise of step s-1 (call 0; for s = 1 that is the call of the reset observation), scaled to 0..4 */
 int orc_noise_action(uint64_t seed, uint32_t env, uint32_t ep, uint32_t step) {
     uint32_t w[4];
-    noise_words(seed, env, ep, step, 0, 3, w);
-    return (int)(((uint64_t)w[0] * 5u) >> 32);
+    noise_words(seed, env, ep, step - 1u, 0, 0, w);
+    return (int)(((uint64_t)w[3] * 5u) >> 32);
 }
 
 /* dqn.py:375-403 _sample_far_start with Philox candidates */
