@@ -1134,6 +1134,56 @@ __global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kerne
     constexpr int kEnvsPerWave = 64 / G;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int unit = wave;
+    // Two scopes of dealing.  (a) Eight workgroups that run on the SAME XCD (workgroup b runs on XCD b mod 8, so the
+    // pool is b0, b0+8, ..., b0+56: the state a CU reads was written through the same L2 one launch earlier) pool their
+    // 128 wave units: the k-th collect unit of the pool goes to pool member k mod 8, wave k div 8, so every CU gets its
+    // share of the pool's collect steps (within +-1) and deals them over its SIMDs.  (b) Otherwise (lane groups narrower
+    // than a wave, a partial last group of workgroups) each workgroup deals its own 16 units.  The bits come from the
+    // words described below: one vector load of 2 words per lane for (a), one scalar load for (b).  In (a) the "n-th
+    // collect / n-th move unit" selection is done lane-parallel (v_mbcnt prefix counts + ballot): the scalar unit is
+    // shared by the 16 waves of a CU, which all run this prologue at the same time.
+    constexpr int kPool = 8, kXcds = 8;
+    const uint32_t span0 = blockIdx.x - blockIdx.x % (kPool * kXcds);             // 64 workgroups = 8 pools
+    const uint32_t pool_b0 = span0 + blockIdx.x % kXcds;                          // first member of this workgroup's pool
+    const bool pooled = (G == 64) & (kWaves == 16) & (span0 + kPool * kXcds <= gridDim.x);
+    bool unit_is_global = false;
+    uint32_t pool_word = 0u;
+    bool have_pool_word = false;
+    if (kWaves == 16 && G == 64 && pooled) {
+        if (balance) {                                               // kernel-uniform
+            const int lane = (int)(threadIdx.x & 63u);
+            // pool unit u = 16 * member + wave unit; lane l looks at units l and 64 + l
+            const uint32_t env_lo = (pool_b0 + kXcds * (uint32_t)(lane >> 4)) * kWaves + (uint32_t)(lane & 15);
+            const uint32_t env_hi = env_lo + 4u * kXcds * kWaves;
+            const bool from_actions = (actions != nullptr) & ((int)((span0 + kPool * kXcds) * kWaves) <= num_envs);
+            const uint32_t* src = from_actions ? reinterpret_cast<const uint32_t*>(actions) : hint_in;
+            const uint32_t w_lo = src[env_lo], w_hi = src[env_hi];
+            const bool bit_lo = (w_lo & 7u) == 4u, bit_hi = (w_hi & 7u) == 4u;
+            const uint64_t m_lo = __ballot(bit_lo), m_hi = __ballot(bit_hi);
+            const int c_lo = __popcll(m_lo), c = c_lo + __popcll(m_hi);
+            const int i = (int)((blockIdx.x - pool_b0) / kXcds);                   // this workgroup's rank in its pool
+            const int c_i = c > i ? (c - i + kPool - 1) / kPool : 0;               // collects k < c with k mod 8 == i
+            const bool want_collect = wave < c_i;
+            const int before = (c / kPool) * i + (c % kPool < i ? c % kPool : i);  // collects of pool members 0..i-1
+            const int target = want_collect ? wave * kPool + i : kWaves * i - before + (wave - c_i);
+            // rank of this lane's two units among the collect (or the move) units of the pool
+            const int ones_lo = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_lo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_lo, 0u));
+            const int ones_hi = c_lo + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_hi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_hi, 0u));
+            const int rank_lo = want_collect ? ones_lo : lane - ones_lo;
+            const int rank_hi = want_collect ? ones_hi : 64 + lane - ones_hi;
+            const uint64_t h_lo = __ballot((bit_lo == want_collect) & (rank_lo == target));
+            const uint64_t h_hi = __ballot((bit_hi == want_collect) & (rank_hi == target));
+            const int pu = h_lo != 0ull ? __ffsll((long long)h_lo) - 1 : 64 + __ffsll((long long)h_hi) - 1;
+            unit = (int)((pool_b0 + kXcds * (uint32_t)(pu >> 4)) * kWaves) + (pu & 15);   // a global unit index
+            unit_is_global = true;
+            // the word of the chosen unit (tagged action of the random policy) sits in lane pu mod 64 already
+            const int src_lane = __builtin_amdgcn_readfirstlane(pu & 63);
+            const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)w_lo, src_lane);
+            const uint32_t wh = (uint32_t)__builtin_amdgcn_readlane((int)w_hi, src_lane);
+            pool_word = pu < 64 ? wl : wh;
+            have_pool_word = !from_actions;
+        }
+    } else
     if (kWaves >= 8) {          // 4-wave workgroups: one wave per SIMD, nothing to deal
         // One word per environment of this workgroup, "== 4" meaning "steps a collect action": the caller's action
         // array, or for the in-kernel random policy the words the PREVIOUS launch left in hint_in (one step ahead draw).
@@ -1155,7 +1205,7 @@ __global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kerne
             unit = __ffs((int)m) - 1;
         }
     }
-    const uint32_t env = (blockIdx.x * kWaves + (uint32_t)unit) * kEnvsPerWave + uni<G>((int)((threadIdx.x & 63u) / G));
+    const uint32_t env = ((unit_is_global ? 0u : blockIdx.x * kWaves) + (uint32_t)unit) * kEnvsPerWave + uni<G>((int)((threadIdx.x & 63u) / G));
     const uint32_t idx = env * G + gl;
     const bool in_batch = env < (uint32_t)num_envs;
     Sensor s;
@@ -1167,7 +1217,7 @@ __global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kerne
     uint32_t next_word = 0u;
     uint32_t hint_word = 0u;
     if (G == 64 && actions == nullptr)
-        hint_word = ((const __attribute__((address_space(4))) uint32_t*)hint_in)[blockIdx.x * kWaves + (uint32_t)unit];
+        hint_word = have_pool_word ? pool_word : ((const __attribute__((address_space(4))) uint32_t*)hint_in)[env];
     // G = 64: the record is wave-uniform and nobody else touches it during the launch, so it is read with scalar loads
     // (constant address space: straight into SGPRs, no v_readfirstlane) and written once by lane 0 at the end.
     if (G == 64) {
