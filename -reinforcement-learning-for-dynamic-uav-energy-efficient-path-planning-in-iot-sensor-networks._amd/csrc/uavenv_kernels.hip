@@ -1142,8 +1142,11 @@ __global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kerne
     // words described below: one vector load of 2 words per lane for (a), one scalar load for (b).  In (a) the "n-th
     // collect / n-th move unit" selection is done lane-parallel (v_mbcnt prefix counts + ballot): the scalar unit is
     // shared by the 16 waves of a CU, which all run this prologue at the same time.
-    constexpr int kPool = 8, kXcds = 8;
-    const uint32_t span0 = blockIdx.x - blockIdx.x % (kPool * kXcds);             // 64 workgroups = 8 pools
+#ifndef UAV_POOL
+#define UAV_POOL 8
+#endif
+    constexpr int kPool = UAV_POOL, kXcds = 8, kWordsPerLane = kPool * 16 / 64;   // pool units = 16 * kPool, 64 per word slot
+    const uint32_t span0 = blockIdx.x - blockIdx.x % (kPool * kXcds);             // kPool * 8 workgroups = 8 pools
     const uint32_t pool_b0 = span0 + blockIdx.x % kXcds;                          // first member of this workgroup's pool
     const bool pooled = (G == 64) & (kWaves == 16) & (span0 + kPool * kXcds <= gridDim.x);
     bool unit_is_global = false;
@@ -1152,35 +1155,41 @@ __global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kerne
     if (kWaves == 16 && G == 64 && pooled) {
         if (balance) {                                               // kernel-uniform
             const int lane = (int)(threadIdx.x & 63u);
-            // pool unit u = 16 * member + wave unit; lane l looks at units l and 64 + l
-            const uint32_t env_lo = (pool_b0 + kXcds * (uint32_t)(lane >> 4)) * kWaves + (uint32_t)(lane & 15);
-            const uint32_t env_hi = env_lo + 4u * kXcds * kWaves;
+            // pool unit u = 16 * member + wave unit; lane l looks at units l, 64 + l, 128 + l, ... (word slot j = u / 64)
             const bool from_actions = (actions != nullptr) & ((int)((span0 + kPool * kXcds) * kWaves) <= num_envs);
             const uint32_t* src = from_actions ? reinterpret_cast<const uint32_t*>(actions) : hint_in;
-            const uint32_t w_lo = src[env_lo], w_hi = src[env_hi];
-            const bool bit_lo = (w_lo & 7u) == 4u, bit_hi = (w_hi & 7u) == 4u;
-            const uint64_t m_lo = __ballot(bit_lo), m_hi = __ballot(bit_hi);
-            const int c_lo = __popcll(m_lo), c = c_lo + __popcll(m_hi);
+            uint32_t w[kWordsPerLane];
+            uint64_t m[kWordsPerLane];
+            bool bit[kWordsPerLane];
+            int c = 0;
+#pragma unroll
+            for (int j = 0; j < kWordsPerLane; j++)
+                w[j] = src[(pool_b0 + kXcds * (uint32_t)(4 * j + (lane >> 4))) * kWaves + (uint32_t)(lane & 15)];
+#pragma unroll
+            for (int j = 0; j < kWordsPerLane; j++) { bit[j] = (w[j] & 7u) == 4u; m[j] = __ballot(bit[j]); c += __popcll(m[j]); }
             const int i = (int)((blockIdx.x - pool_b0) / kXcds);                   // this workgroup's rank in its pool
-            const int c_i = c > i ? (c - i + kPool - 1) / kPool : 0;               // collects k < c with k mod 8 == i
+            const int c_i = c > i ? (c - i + kPool - 1) / kPool : 0;               // collects k < c with k mod kPool == i
             const bool want_collect = wave < c_i;
             const int before = (c / kPool) * i + (c % kPool < i ? c % kPool : i);  // collects of pool members 0..i-1
             const int target = want_collect ? wave * kPool + i : kWaves * i - before + (wave - c_i);
-            // rank of this lane's two units among the collect (or the move) units of the pool
-            const int ones_lo = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_lo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_lo, 0u));
-            const int ones_hi = c_lo + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_hi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_hi, 0u));
-            const int rank_lo = want_collect ? ones_lo : lane - ones_lo;
-            const int rank_hi = want_collect ? ones_hi : 64 + lane - ones_hi;
-            const uint64_t h_lo = __ballot((bit_lo == want_collect) & (rank_lo == target));
-            const uint64_t h_hi = __ballot((bit_hi == want_collect) & (rank_hi == target));
-            const int pu = h_lo != 0ull ? __ffsll((long long)h_lo) - 1 : 64 + __ffsll((long long)h_hi) - 1;
+            // rank of each of this lane's units among the collect (or the move) units of the pool; exactly one unit hits
+            int pu = 0, ones_below = 0;
+            uint32_t word = 0u;
+#pragma unroll
+            for (int j = 0; j < kWordsPerLane; j++) {
+                const int ones = ones_below + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[j], 0u));
+                const int rank = want_collect ? ones : 64 * j + lane - ones;
+                const uint64_t h = __ballot((bit[j] == want_collect) & (rank == target));
+                if (h != 0ull) {                                             // wave-uniform
+                    const int l = __ffsll((long long)h) - 1;
+                    pu = 64 * j + l;
+                    word = (uint32_t)__builtin_amdgcn_readlane((int)w[j], l);  // the chosen unit's word sits in lane l
+                }
+                ones_below += __popcll(m[j]);
+            }
             unit = (int)((pool_b0 + kXcds * (uint32_t)(pu >> 4)) * kWaves) + (pu & 15);   // a global unit index
             unit_is_global = true;
-            // the word of the chosen unit (tagged action of the random policy) sits in lane pu mod 64 already
-            const int src_lane = __builtin_amdgcn_readfirstlane(pu & 63);
-            const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)w_lo, src_lane);
-            const uint32_t wh = (uint32_t)__builtin_amdgcn_readlane((int)w_hi, src_lane);
-            pool_word = pu < 64 ? wl : wh;
+            pool_word = word;
             have_pool_word = !from_actions;
         }
     } else
