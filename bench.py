@@ -101,7 +101,7 @@ def main():
     ap.add_argument("--sensors", type=int, default=50)
     ap.add_argument("--grid", type=int, default=500)
     ap.add_argument("--exchange", choices=["auto", "none", "allgather"], default="auto")
-    ap.add_argument("--ring", type=int, default=32, help="replay-ring slots used by the bench (two chunks)")
+    ap.add_argument("--ring", type=int, default=128, help="replay-ring slots used by the bench (two chunks = two HIP graphs / collectives)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of replaying HIP graphs")
     ap.add_argument("--fused", type=int, default=16, help="steps per launch of the additional fused-rollout measurement (0 = skip)")
