@@ -133,7 +133,7 @@ enum { UAVENV_TAPE_ZA = 0, UAVENV_TAPE_ZB, UAVENV_TAPE_U, UAVENV_TAPE_ZC, UAVENV
 
 /* action sources for uavenv_step_policy / uavenv_rollout */
 #define UAVENV_POLICY_ACTIONS            0   /* actions_dev                                                   */
-#define UAVENV_POLICY_RANDOM             1   /* uniform random (Philox call 3), BASELINE.md section 4         */
+#define UAVENV_POLICY_RANDOM             1   /* uniform random (lane 0's spare Philox word), BASELINE.md sec. 4 */
 #define UAVENV_POLICY_NEAREST            2   /* greedy_agents.py:73-100  NearestSensorGreedy, on device       */
 #define UAVENV_POLICY_MAX_THROUGHPUT_V2  3   /* greedy_agents.py:105-216 MaxThroughputGreedyV2, on device     */
 enum { UAVENV_RTAPE_FILL = 0, UAVENV_RTAPE_ZD, UAVENV_RTAPE_ZE, UAVENV_RTAPE_SLOTS };
@@ -199,7 +199,8 @@ int uavenv_reset(UavEnv* env, const uint8_t* mask_dev, float* obs_out_dev, void*
 int uavenv_step(UavEnv* env, const int32_t* actions_dev, float* obs_out_dev, double* reward_out_dev,
                 float* reward32_out_dev, uint8_t* done_out_dev, float* terminal_obs_dev, void* stream);
 
-/* same, with the uniform-random policy of BASELINE.md section 4 drawn in-kernel (Philox call 3);
+/* same, with the uniform-random policy of BASELINE.md section 4 drawn in-kernel (word 3 of lane 0's
+ * observation-noise call of the previous step);
  * actions_out_dev (int32 [E], nullable) receives the actions taken. */
 int uavenv_step_random(UavEnv* env, int32_t* actions_out_dev, float* obs_out_dev, double* reward_out_dev,
                        float* reward32_out_dev, uint8_t* done_out_dev, float* terminal_obs_dev, void* stream);
