@@ -328,7 +328,7 @@ static int step_common(UavEnv* e, int32_t policy, const int32_t* actions, int32_
                e->term_pool, e->term_counter, e->term_index, e->term_rows, policy, e->aux_out, nullptr, nullptr, 0};
     a.hint_in = e->hints + (size_t)e->hint_parity * (size_t)e->padded_envs;          // always a readable buffer
     a.balance = e->balance ? 1 : 0;
-    if (policy == UAVENV_POLICY_RANDOM && e->G == 64) {           // this launch leaves the next launch's action words
+    if (policy == UAVENV_POLICY_RANDOM) {                         // this launch leaves the next launch's action words
         a.hint_out = e->hints + (size_t)(e->hint_parity ^ 1) * (size_t)e->padded_envs;
         e->hint_parity ^= 1;
     } else if (policy != UAVENV_POLICY_ACTIONS) a.balance = 0;   // no cheap way to know the actions up front

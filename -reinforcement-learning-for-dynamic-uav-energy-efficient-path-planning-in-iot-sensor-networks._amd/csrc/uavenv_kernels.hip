@@ -746,8 +746,15 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
         action = (int)((e.env_index * 7u + step * 3u + e.episode) % 5u);
         (void)hint_word;
 #else
-        if (G == 64 && (hint_word & ~7u) == hint_tag(e.episode, step)) action = (int)(hint_word & 7u);   // drawn last launch
-        else action = random_action(noise_words(c.seed, e.env_index, e.episode, step - 1u, 0u, 0).w3);   // not handed over: draw it
+        const bool word_ok = (hint_word & ~7u) == hint_tag(e.episode, step);       // handed over by the last launch / step
+        if (G == 64) {                                                            // wave-uniform
+            if (word_ok) action = (int)(hint_word & 7u);
+            else action = random_action(noise_words(c.seed, e.env_index, e.episode, step - 1u, 0u, 0).w3);   // draw it
+        } else {
+            int drawn = 0;
+            if (__any(!word_ok)) drawn = random_action(noise_words(c.seed, e.env_index, e.episode, step - 1u, 0u, 0).w3);
+            action = word_ok ? (int)(hint_word & 7u) : drawn;
+        }
 #endif
         if (a.actions_out != nullptr && in_batch && gl == 0) a.actions_out[out] = action;
     }
@@ -1083,15 +1090,22 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
     // 0's spare word of the observation-noise call made above.  The step kernel leaves it for the next launch (which uses
     // it for scheduling and, after checking the tag against the record, as the action); the rollout kernel carries it.
     next_word = 0u;
-    if (G == 64 && UAV_POLICY(a) == UAVENV_POLICY_RANDOM) {
+    if (UAV_POLICY(a) == UAVENV_POLICY_RANDOM) {
         const uint32_t ns = (uint32_t)(r.current_step + 1);
 #ifdef UAV_ABL_CHEAPACTION
         const uint32_t na = (r.env_index * 7u + ns * 3u + r.episode) % 5u;
 #else
-        const bool was_reset = __any(do_reset) != 0;                               // wave-uniform (G = 64)
-        const bool have = was_reset ? have_reset_w3 : z.have_w3;
-        uint32_t w3n = (uint32_t)__builtin_amdgcn_readlane((int)(was_reset ? reset_w3 : z.w3), 0);
-        if (!have) w3n = noise_words(c.seed, r.env_index, r.episode, ns - 1u, 0u, 0).w3;   // noise came from a tape: draw it
+        uint32_t w3n;
+        if (G == 64) {
+            const bool was_reset = __any(do_reset) != 0;                           // wave-uniform
+            const bool have = was_reset ? have_reset_w3 : z.have_w3;
+            w3n = (uint32_t)__builtin_amdgcn_readlane((int)(was_reset ? reset_w3 : z.w3), 0);
+            if (!have) w3n = noise_words(c.seed, r.env_index, r.episode, ns - 1u, 0u, 0).w3;   // noise came from a tape: draw it
+        } else {
+            const bool have = do_reset ? have_reset_w3 : z.have_w3;                // uniform within a lane group
+            w3n = gshfl<G>(do_reset ? reset_w3 : z.w3, 0);                         // the group's lane 0
+            if (__any(!have)) { const uint32_t dw = noise_words(c.seed, r.env_index, r.episode, ns - 1u, 0u, 0).w3; w3n = have ? w3n : dw; }
+        }
         const uint32_t na = (uint32_t)random_action(w3n);
 #endif
         next_word = na | hint_tag(r.episode, ns);
@@ -1227,6 +1241,7 @@ __global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kerne
     uint32_t hint_word = 0u;
     if (G == 64 && actions == nullptr)
         hint_word = have_pool_word ? pool_word : ((const __attribute__((address_space(4))) uint32_t*)hint_in)[env];
+    else if (actions == nullptr) hint_word = hint_in[env];              // narrower lane groups: one word per group, vector load
     // G = 64: the record is wave-uniform and nobody else touches it during the launch, so it is read with scalar loads
     // (constant address space: straight into SGPRs, no v_readfirstlane) and written once by lane 0 at the end.
     if (G == 64) {
