@@ -137,10 +137,16 @@ def main():
     if not distributed:
         exchange = "none"
     use_graph = not args.no_graph
-    L = max(1, args.ring // 2) if use_graph else 1       # slots per chunk = per HIP graph = per collective
+    # slots per chunk = steps per HIP graph = steps per collective: half the ring, but short runs get shorter chunks
+    # so that most of their steps are still replayed rather than launched one by one
+    L = 1
+    if use_graph:
+        while 2 * L <= min(max(1, args.ring // 2), max(1, K // 4)):
+            L *= 2
+    ring_slots = 2 * L if use_graph else args.ring
 
     def make_ring(shared):
-        r_ = TransitionRing(args.ring, E, env.obs_dim, dev, world_size=world if shared else 1, rank=rank if shared else 0,
+        r_ = TransitionRing(ring_slots, E, env.obs_dim, dev, world_size=world if shared else 1, rank=rank if shared else 0,
                             chunk_len=L, always_exchange=shared and selftest)
         r_.attach(env)    # the kernel writes obs AND (action, reward, done, terminal row) straight into the ring slot
         return r_
