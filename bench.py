@@ -222,6 +222,25 @@ def main():
     kern_ms = env.time_steps(min(K, 1000))
     torch.cuda.synchronize(dev)
 
+    # Additional measurement for N > 1 (never `value`): the same K steps WITHOUT the exchange, every rank filling a ring of
+    # its own.  The exchange replicates every observation on every GPU (2.6 MB per rank and step) and is bound by the
+    # xGMI links, not by the step; this number shows how the sharded path itself scales.
+    shard_only = None
+    if exchange == "allgather":
+        ring.drain()
+        ring = make_ring(False)
+        graphs = ring.capture_chunks(lambda slot: env.step_random(obs_out=slot)) if use_graph else None
+        run_steps(W, align=True)
+        barrier()
+        t1 = time.perf_counter()
+        run_steps(K)
+        barrier()
+        dt1 = time.perf_counter() - t1
+        t = torch.tensor([dt1], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        shard_only = {"env_steps_per_s": E * world * K / float(t.item()), "ms_per_step": float(t.item()) / K * 1e3,
+                      "note": "same steps, no all-gather (per-rank replay rings)"}
+
     # Additional measurement (never `value`): the fused rollout entry point, `--fused` steps per launch, writing
     # every step's obs/reward/done block into consecutive ring slots.  Same results bit for bit.
     fused = None
@@ -277,6 +296,8 @@ def main():
     }
     if fused:
         out["fused_rollout"] = fused
+    if shard_only:
+        out["shard_only"] = shard_only
     if distributed and exchange_error:
         out["config"]["exchange_error"] = exchange_error
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
