@@ -92,6 +92,21 @@ def latest_traffic(workload_key):
     return best
 
 
+def latest_valu_per_wave():
+    """VALU instructions per wavefront of the step kernel from the committed SQ-counter summary
+    (profiles/*sq_counters*.txt, tools/pmc_rollout.sh), or None."""
+    best = None
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*sq_counters*.txt"))):
+        try:
+            for line in open(p):
+                f = line.split()
+                if len(f) >= 5 and f[0] == "step" and f[1] == "SQ_INSTS_VALU":
+                    best = float(f[4])
+        except Exception:
+            pass
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -293,6 +308,12 @@ def main():
                      "timed_region_event_ms_per_step": ev_ms / K,
                      "note": "path is VALU/latency bound (Philox + float64 physics per sensor), not HBM bound: "
                              "see DESIGN.md"},
+        # what the launch is actually bound by, for context (not a roofline the contract asks for): share of the chip's
+        # VALU issue slots the launch uses = instructions per wave (committed SQ counters, 4 cycles each on a SIMD) x waves
+        # / (1024 SIMDs x 2.4 GHz x launch duration)
+        "valu_issue": (None if latest_valu_per_wave() is None or n != 50 or E != 4096 else
+                       {"valu_insts_per_wave": latest_valu_per_wave(),
+                        "frac_of_issue_slots": latest_valu_per_wave() * 4.0 * (E * 64 // 64) / (1024 * 2.4e9 * kern_ms * 1e-3)}),
     }
     if fused:
         out["fused_rollout"] = fused
