@@ -1,0 +1,31 @@
+"""GPU: bench.py prints ONE JSON line with the fields the driver's contract names (short run)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_has_the_contract_fields():
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "96", "--warmup", "16",
+                                   "--fused", "4", "--no-cpu-baseline"], text=True, stderr=subprocess.DEVNULL, cwd=ROOT)
+    lines = [l for l in out.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    baseline = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["metric"] == baseline["metric"] and d["unit"] == "env-steps/s"
+    assert d["n_gpus"] == 1 and d["steps"] == 96 and d["warmup"] == 16 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert abs(d["ms_per_step"] * 1e-3 * d["value"] - 4096) < 1e-3 * 4096          # value = envs / time per step
+    assert d["value"] > 2e6                                                       # north_star target on one GPU
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert r["algorithmic_bytes_per_env_step"] == 68 * 50 + 104
+    assert "cpu_baseline" in d and d["fused_rollout"]["steps_per_launch"] == 4
