@@ -65,6 +65,19 @@ def test_step_is_hip_graph_capturable():
     assert torch.equal(a.obs, b.obs) and torch.equal(a.reward, b.reward) and torch.equal(a.done, b.done)
     sa, sb = a.state_dict(), b.state_dict()
     assert all(torch.equal(sa[k], sb[k]) for k in sa)
+    # an ODD number of random-policy steps per graph: the replays read action words that are two launches old (the
+    # launch parity is baked into the graph); their (episode, step) tags no longer match, so the kernel must draw the
+    # actions itself -- same results
+    g3 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g3):
+        for _ in range(3):
+            a.step_random()
+    for rep in range(4):
+        g3.replay()
+        for _ in range(3):
+            b.step_random()
+        torch.cuda.synchronize()
+        assert torch.equal(a.obs, b.obs) and torch.equal(a.reward, b.reward) and torch.equal(a.actions_taken, b.actions_taken)
     a.close(); b.close()
 
 
