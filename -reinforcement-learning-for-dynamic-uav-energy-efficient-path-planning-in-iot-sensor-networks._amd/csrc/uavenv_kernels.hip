@@ -1083,7 +1083,21 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
         }
         wrote_pos |= draw_layout && do_reset;
     }
-    if (kRegs) *rec_out = r; else if (gl == 0) *rec_out = r;
+    if (kRegs) *rec_out = r;
+    else if (gl == 0) {
+#ifndef UAV_ABL_FULLREC
+        // words 24..31 (grid height, sensor count, env index, status, reciprocals) only change at a reset or on an
+        // invalid action: without either (decided per wave when the group is the wave) the first 96 bytes are all there is
+        if (G == 64 && !(__any(do_reset) != 0 || status_bits != 0u)) {
+            union { UavEnvRecord rec; uint4 q[8]; } u;
+            u.rec = r;
+            uint4* dst = reinterpret_cast<uint4*>(rec_out);
+#pragma unroll
+            for (int i = 0; i < 6; i++) dst[i] = u.q[i];
+        } else
+#endif
+            *rec_out = r;
+    }
     live |= gl < r.num_sensors;
     status_or |= r.status;
     // The action this environment draws NEXT (after a possible auto-reset: exact), tagged with its (episode, step): lane
