@@ -140,8 +140,8 @@ class BatchedUAVEnv:
         N.check(self.L.uavenv_set_grid_choices(self._h, len(grids), w, h), self._h)
 
     def set_noise_tape(self, step_tape=None, reset_tape=None):
-        """step_tape: float32 cuda [E, 7, lane_stride]; reset_tape: [E, 3, lane_stride]; None = Philox."""
-        for t, slots in ((step_tape, 7), (reset_tape, 3)):
+        """step_tape: float32 cuda [E, 7, lane_stride]; reset_tape: [E, 4, lane_stride]; None = Philox."""
+        for t, slots in ((step_tape, 7), (reset_tape, 4)):
             if t is not None:
                 assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
                 assert tuple(t.shape) == (self.num_envs, slots, self.lane_stride), tuple(t.shape)
@@ -168,7 +168,7 @@ class BatchedUAVEnv:
     def dump_noise(self):
         E, G = self.num_envs, self.lane_stride
         st = torch.empty(E, 7, G, dtype=torch.float32, device=self.device)
-        rt = torch.empty(E, 3, G, dtype=torch.float32, device=self.device)
+        rt = torch.empty(E, 4, G, dtype=torch.float32, device=self.device)
         N.check(self.L.uavenv_dump_noise(self._h, self._p(st), self._p(rt), self._stream()), self._h)
         return st, rt
 

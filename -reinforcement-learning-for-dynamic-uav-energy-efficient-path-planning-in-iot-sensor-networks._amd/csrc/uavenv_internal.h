@@ -70,7 +70,7 @@ struct Ptrs {
     UavEnvRecord* rec;
     UavEnvEpisodeStats* stats;
     const float* step_tape;     // [E][6][G] or nullptr
-    const float* reset_tape;    // [E][3][G] or nullptr
+    const float* reset_tape;    // [E][4][G] or nullptr
     uint32_t* status;           // device word: OR of per-env status bits
     unsigned long long* stamps; // diagnostic build only (-DUAVENV_STAMPS): 8 words per wavefront, else unused
 };

@@ -5,10 +5,10 @@
 // instance, one lane owns one sensor.  64/G environments share a wavefront, 256/G a workgroup.
 // Per-sensor state is SoA [E][G] in HBM (every wave-load is one contiguous 256..512 B row per
 // array), lives in VGPRs for the whole step, and is written back once.  Reductions over sensors
-// (data-loss sum, Capture-Effect top-2, variance, urgency sums, Jain's sums) are wavefront
-// butterfly shuffles / ballots restricted to the group.  The observation row is transposed
-// through LDS so the [E][obs_dim] float32 write is coalesced.  No MFMA: the path is elementwise +
-// short reductions.
+// (data-loss sum, Capture-Effect top-2, variance, urgency sums, Jain's sums) are DPP row butterflies,
+// v_readlane and ballots restricted to the group.  Every lane stores its own sensor's slice of the
+// [E][obs_dim] float32 observation row (the lanes of a group cover the row contiguously, so the stores
+// coalesce with no staging).  No LDS, no MFMA: the path is elementwise + short reductions.
 //
 // Reference being replaced (paths relative to /root/reference/src/):
 //   environment/uav_env.py       step :429-488, _execute_move_action :494-516,
@@ -387,11 +387,12 @@ template <int G> __device__ __forceinline__ double dist_nearest_with_data(const 
 
 // dqn.py:446-451 Jain's index over r_i = 100*tx_i/gen_i (gen_i > 0); also returns the population
 // std of the rates (dqn.py:324 fairness_std)
-template <int G> __device__ __forceinline__ double jains_index(const Sensor& s, bool act, double* std_out) {
+template <int G> __device__ __forceinline__ double jains_index(const Sensor& s, bool act, double* std_out, int* count_out = nullptr) {
     bool ok = act && s.gen > 0;
     double r = ok ? (s.tx / s.gen) * 100 : 0.0;
     double s1 = gsum<G>(r), s2 = gsum<G>(r * r);
     int cnt = __popcll(gballot<G>(ok));
+    if (count_out) *count_out = cnt;
     if (std_out) {
         double mean = cnt > 0 ? s1 / cnt : 0.0;
         double dv = ok ? (r - mean) * (r - mean) : 0.0;
@@ -581,16 +582,36 @@ __device__ __forceinline__ void reset_group(CRef c, const P& p, Sensor& s, UavEn
         r.inv_grid_w = 1.0 / (double)gw; r.inv_grid_h = 1.0 / (double)gh;
     }
     float fill_u = u24(w.w0);
+    float zS = 0.f;
     if (UAV_TAPE(p.reset_tape) != nullptr) {
         fill_u = 0.f; zD = 0.f; zE = 0.f;
         if (in_batch) {
             const float* t = p.reset_tape + env * (size_t)(UAVENV_RTAPE_SLOTS * G) + gl;
-            fill_u = t[0 * G]; zD = t[1 * G]; zE = t[2 * G];
+            fill_u = t[UAVENV_RTAPE_FILL * G]; zD = t[UAVENV_RTAPE_ZD * G]; zE = t[UAVENV_RTAPE_ZE * G];
+            zS = t[UAVENV_RTAPE_ZS * G - gl];                                      // element 0 of the row
         }
     } else {
         Words4 v = noise_words(c.seed, r.env_index, ep, 0u, (uint32_t)gl, 0);
         normal_pair(v.w0, v.w1, zD, zE);
         w3 = v.w3; have_w3 = true;
+    }
+    // dqn.py:340-351: the fresh sensors of a DomainRandEnv episode inherit `s0.spreading_factor` -- the SF the OLD sensor 0
+    // got from the discarded super().reset(): back to SF 12 without an EMA sample (iot_sensors.py:309-311), then one
+    // update_spreading_factor in the reset observation (uav_env.py:427 -> :654) with the UAV at the PREVIOUS episode's
+    // start (uav.py:256): avg = cur, SF by the threshold list, 12 kept when none fires (iot_sensors.py:239-255).
+    // Evaluated here, while `s` / `r` still hold the old layout and start; its shadowing sample zS is lane 0 of Philox call 6.
+    uint32_t fresh_sf = 12u;
+    if (UAV_FLAGS(c) & UAVENV_FLAG_RANDOM_LAYOUT) {
+        if (UAV_TAPE(p.reset_tape) == nullptr) {
+            const Words4 q = noise_words(c.seed, r.env_index, ep, 0u, 0u, 6);
+            float spare;
+            normal_pair(q.w0, q.w1, zS, spare);
+        }
+        const float sx0 = gshfl<G>(s.sx, 0), sy0 = gshfl<G>(s.sy, 0);
+        const double avg0 = rssi_deterministic(c, r.start_x, r.start_y, sx0, sy0) + c.sigma * (double)zS;
+        fresh_sf = avg0 > c.sf_thr[2] ? 11u : fresh_sf;
+        fresh_sf = avg0 > c.sf_thr[1] ? 9u : fresh_sf;
+        fresh_sf = avg0 > c.sf_thr[0] ? 7u : fresh_sf;
     }
     if (draw_layout) {                                                             // uav_env.py:366-374 / dqn.py:342-344
         s.sx = u24(w.w1) * (float)r.grid_w;
@@ -602,7 +623,7 @@ __device__ __forceinline__ void reset_group(CRef c, const P& p, Sensor& s, UavEn
     s.gen = s.b;                                                                   // :316
     s.tx = 0.0; s.lost = 0.0; s.avg = 0.0;                                         // :311,317-318
     s.flags = (s.flags & kDataCollected) | 12u;                                    // :309 SF12; visited cleared (uav_env.py:416)
-    if (UAV_FLAGS(c) & UAVENV_FLAG_RANDOM_LAYOUT) { s.b = 0.0; s.gen = 0.0; s.flags = 12u; }   // dqn.py:346-360 fresh sensors
+    if (UAV_FLAGS(c) & UAVENV_FLAG_RANDOM_LAYOUT) { s.b = 0.0; s.gen = 0.0; s.flags = fresh_sf; }   // dqn.py:346-360 fresh sensors
     r.battery = c.maxb;                                                            // uav.py:257
     r.current_step = 0; r.total_reward = 0.0; r.total_data_collected = 0.0;        // uav_env.py:413-415
     r.last_step_bytes = 0.0; r.capture_triggers = 0; r.boundary_hits = 0;          // :419-422
@@ -707,9 +728,9 @@ __global__ __launch_bounds__(kSmallBlockThreads) void uav_reset_kernel(const Con
 }
 
 // ---------------------------------------------------------------------------------------------
-// One environment step for one lane group: the hot path.  Shared by the single-step kernel (record in
-// global memory) and the fused rollout kernel (record staged in LDS, sensor state kept in registers
-// across steps).  `rec` may point to global memory or LDS.
+// One environment step for one lane group: the hot path.  Shared by the single-step kernel (record read from
+// global memory, through the scalar cache when G = 64) and the fused rollout kernel (kRegs: record and sensor
+// state kept in registers across steps, `rec` / `rec_out` point at the kernel's private copy).
 // ---------------------------------------------------------------------------------------------
 // The uniform-random policy's action of step s is word 3 of the Philox call that lane 0 makes ANYWAY for the observation
 // noise of step s-1 (call 0; for s = 1 the call of the reset observation): the policy costs no generator call of its own.
@@ -1039,7 +1060,11 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
     }
     r.first_full_coverage_step = ((r.first_full_coverage_step < 0) & (visited_cnt == n)) ? e.step
                                                                                        : r.first_full_coverage_step;
-    if (UAV_FLAGS(c) & UAVENV_FLAG_JAIN_BONUS) reward += c.jain_weight * (jains_index<G>(s, act, nullptr) - 0.5) / n;
+    if (UAV_FLAGS(c) & UAVENV_FLAG_JAIN_BONUS) {                                  // dqn.py:434-442
+        int rated;
+        const double j = jains_index<G>(s, act, nullptr, &rated);
+        reward = rated > 0 ? reward + c.jain_weight * (j - 0.5) / n : reward;     // `if rates:` no bonus before any sensor generated data
+    }
     r.episode_return += reward;
 
     if (in_batch && gl == 0) {
@@ -1353,8 +1378,12 @@ __global__ __launch_bounds__(kSmallBlockThreads) void uav_dump_noise_kernel(cons
         Words4 v = noise_words(c.seed, r.env_index, ep, 0u, (uint32_t)gl, 0);
         float zD, zE;
         normal_pair(v.w0, v.w1, zD, zE);
+        const Words4 q = noise_words(c.seed, r.env_index, ep, 0u, 0u, 6);
+        float zS, spare;
+        normal_pair(q.w0, q.w1, zS, spare);
         float* t = reset_tape + env * (size_t)(UAVENV_RTAPE_SLOTS * G) + gl;
-        t[0 * G] = u24(w.w0); t[1 * G] = zD; t[2 * G] = zE;
+        t[UAVENV_RTAPE_FILL * G] = u24(w.w0); t[UAVENV_RTAPE_ZD * G] = zD; t[UAVENV_RTAPE_ZE * G] = zE;
+        t[UAVENV_RTAPE_ZS * G] = gl == 0 ? zS : 0.0f;
     }
 }
 

@@ -12,6 +12,8 @@
 //   call 2 (reset, step 0):      w0 -> buffer-fill uniform; w1,w2 -> sensor layout x,y;
 //                                lane 0's w3 -> curriculum grid choice
 //   call 4 (lane field = try):   w0,w1 -> far-start candidate
+//   call 5 (policy steps):       w0,w1 -> (zP, -) in-range sample drawn by a heuristic policy before the step
+//   call 6 (reset, lane 0):      w0,w1 -> (zS, -) the sample behind the SF that fresh DomainRandEnv sensors inherit
 //
 // Normals come from a Box-Muller transform written WITHOUT transcendental instructions: only IEEE
 // float32 +,-,*,fma,sqrt and integer ops in a fixed order, compiled with -ffp-contract=off, so the

@@ -42,10 +42,10 @@ extern "C" {
 #define UAVENV_E_ALLOC        -4
 
 /* UavEnvConfig.flags */
-#define UAVENV_FLAG_RANDOM_LAYOUT  1u   /* dqn.py:342-360 fresh uniform layout + empty buffers per reset */
+#define UAVENV_FLAG_RANDOM_LAYOUT  1u   /* dqn.py:340-360 fresh uniform layout, empty buffers, SF inherited from the old sensor 0 */
 #define UAVENV_FLAG_FAR_START      2u   /* dqn.py:364-365,375-403 rejection-sampled UAV start            */
 #define UAVENV_FLAG_PROX_SHAPING   4u   /* dqn.py:417-425 proximity shaping reward                       */
-#define UAVENV_FLAG_JAIN_BONUS     8u   /* dqn.py:434-442 per-step Jain's fairness bonus                 */
+#define UAVENV_FLAG_JAIN_BONUS     8u   /* dqn.py:434-442 per-step Jain's fairness bonus (once a sensor has generated data) */
 #define UAVENV_FLAG_AUTO_RESET    16u   /* SB3 VecEnv semantics: reset inside step() on truncation        */
 
 /* Every constant of the path is a runtime parameter.  Defaults (uavenv_default_config)
@@ -136,7 +136,9 @@ enum { UAVENV_TAPE_ZA = 0, UAVENV_TAPE_ZB, UAVENV_TAPE_U, UAVENV_TAPE_ZC, UAVENV
 #define UAVENV_POLICY_RANDOM             1   /* uniform random (lane 0's spare Philox word), BASELINE.md sec. 4 */
 #define UAVENV_POLICY_NEAREST            2   /* greedy_agents.py:73-100  NearestSensorGreedy, on device       */
 #define UAVENV_POLICY_MAX_THROUGHPUT_V2  3   /* greedy_agents.py:105-216 MaxThroughputGreedyV2, on device     */
-enum { UAVENV_RTAPE_FILL = 0, UAVENV_RTAPE_ZD, UAVENV_RTAPE_ZE, UAVENV_RTAPE_SLOTS };
+/* reset tape: buffer-fill uniform, (zD, zE) of the reset observation, and zS (element 0 only): the ADR sample the DISCARDED
+ * reset observation of DomainRandEnv.reset draws for the OLD sensor 0, whose SF the fresh sensors inherit (dqn.py:340-351) */
+enum { UAVENV_RTAPE_FILL = 0, UAVENV_RTAPE_ZD, UAVENV_RTAPE_ZE, UAVENV_RTAPE_ZS, UAVENV_RTAPE_SLOTS };
 
 typedef struct UavEnv UavEnv;
 
@@ -173,7 +175,7 @@ int uavenv_set_grid_choices(UavEnv* env, int32_t count, const int32_t* w, const 
 
 /* ---- noise tape (parity testing) ------------------------------------------------------------ */
 /* step_tape_dev: float [E][7][stride] consumed by the next uavenv_step; reset_tape_dev:
- * float [E][3][stride] consumed by uavenv_reset and by auto-resets.  NULL restores Philox. */
+ * float [E][4][stride] consumed by uavenv_reset and by auto-resets.  NULL restores Philox. */
 int uavenv_set_noise_tape(UavEnv* env, const float* step_tape_dev, const float* reset_tape_dev);
 /* writes the tapes the NEXT step (and a reset opening the next episode) would draw from Philox */
 int uavenv_dump_noise(UavEnv* env, float* step_tape_out_dev, float* reset_tape_out_dev, void* stream);

@@ -174,7 +174,9 @@ class OracleEnv:
         self.obs_dim = self.L.orc_obs_dim(C.byref(cfg), n)
 
     def reset_tape(self, rt):
-        rt = np.ascontiguousarray(rt, np.float32); assert rt.shape == (3, self.n)
+        rt = np.ascontiguousarray(rt, np.float32); assert rt.shape in ((3, self.n), (4, self.n))
+        if rt.shape[0] == 3:            # no zS row (only DomainRandEnv's fresh sensors read it): zeros
+            rt = np.concatenate([rt, np.zeros((1, self.n), np.float32)])
         obs = np.empty(self.obs_dim, np.float32)
         self.L.orc_reset_tape(C.byref(self.e), _fp(rt), _fp(obs))
         return obs

@@ -314,11 +314,29 @@ void orc_init(OrcEnv* e, const OrcConfig* c, uint32_t env_index, const float* po
     e->first_full_coverage_step = -1;
 }
 
+/* dqn.py:340-351: DomainRandEnv.reset builds its fresh sensors with `spreading_factor = s0.spreading_factor`,
+ * where s0 is the OLD sensor 0 AFTER the discarded `super().reset()` (dqn.py:340): IoTSensor.reset put it
+ * back to SF 12 with no EMA sample (iot_sensors.py:309-311), uav.reset() moved the UAV to uav.start_position
+ * = the PREVIOUS episode's start (uav.py:256), and the reset observation (uav_env.py:427 -> :654) ran
+ * update_spreading_factor once on it: avg = cur (first sample, iot_sensors.py:239-240), SF by the threshold
+ * list, 12 kept when none fires (:251-255).  zS is that call's shadowing sample.  Must be evaluated BEFORE the
+ * layout / start position of the new episode replace the old ones. */
+static int inherited_sf(const OrcEnv* e, double zS) {
+    const OrcConfig* c = &e->cfg;
+    double det = orc_rssi_deterministic(c, e->start_x, e->start_y, e->pos_x[0], e->pos_y[0]);
+    double avg = det + (0.0 + c->shadowing_std_db * zS);
+    static const int sf_of[4] = {7, 9, 11, 12};
+    int sf = 12;
+    for (int k = 0; k < 4; k++)
+        if (avg > c->sf_thresholds[k]) { sf = sf_of[k]; break; }
+    return sf;
+}
+
 /* uav_env.py:400-427 reset + iot_sensors.py:305-321 IoTSensor.reset + uav.py:241-258 UAV.reset.
  * `fill_u`: the uniform behind np_random.uniform(0.20, 0.60) = lo + (hi-lo)*u (:410).
  * Under ORC_FLAG_RANDOM_LAYOUT (dqn.py:342-360) the sensors are REPLACED by fresh objects:
- * buffer 0, generated 0, SF 12, no EMA sample -- the prefill is discarded. */
-static void reset_common(OrcEnv* e, const float* fill_u) {
+ * buffer 0, generated 0, no EMA sample, SF = `fresh_sf` (inherited_sf above) -- the prefill is discarded. */
+static void reset_common(OrcEnv* e, const float* fill_u, int fresh_sf) {
     const OrcConfig* c = &e->cfg;
     e->episode += 1u;
     e->uav_x = e->start_x; e->uav_y = e->start_y;                   /* uav.py:256 */
@@ -335,6 +353,7 @@ static void reset_common(OrcEnv* e, const float* fill_u) {
         /* data_collected is NOT cleared by IoTSensor.reset (it is by object replacement) */
         if (c->flags & ORC_FLAG_RANDOM_LAYOUT) {
             e->buffer[i] = 0.0; e->gen[i] = 0.0; e->data_collected[i] = 0;
+            e->sf[i] = fresh_sf;                                    /* dqn.py:351 */
         }
     }
     e->current_step = 0; e->total_reward = 0.0; e->total_data_collected = 0.0;    /* :413-415 */
@@ -345,7 +364,7 @@ static void reset_common(OrcEnv* e, const float* fill_u) {
 
 void orc_reset_tape(OrcEnv* e, const float* rt, float* obs_out) {
     int n = e->n;
-    reset_common(e, rt + 0 * n);
+    reset_common(e, rt + 0 * n, inherited_sf(e, (double)rt[3 * n + 0]));
     build_observation(e, rt + 1 * n, rt + 2 * n, obs_out);          /* :427 */
     e->prev_dist_nearest = dist_nearest_with_data(e);               /* dqn.py:368 */
 }
@@ -487,12 +506,13 @@ static double execute_collect(OrcEnv* e, const float* zA, const float* zB, const
 }
 
 /* dqn.py:446-451 _jains over r_i = 100*tx_i/gen_i for gen_i > 0 */
-static double jains_index(const OrcEnv* e) {
+static double jains_index(const OrcEnv* e, int* count_out) {
     double s1 = 0.0, s2 = 0.0; int cnt = 0;
     for (int i = 0; i < e->n; i++) {
         double g = e->gen[i];
         if (g > 0) { double r = (e->tx[i] / g) * 100; s1 += r; s2 += r * r; cnt++; }
     }
+    if (count_out) *count_out = cnt;
     if (cnt > 0 && s2 > 0) return (s1 * s1) / (cnt * s2);
     return 1.0;
 }
@@ -560,8 +580,11 @@ int orc_step_tape(OrcEnv* e, int action, const float* tp, float* obs_out, double
         for (int i = 0; i < n; i++) visited += e->visited[i];
         if (visited == n) e->first_full_coverage_step = e->current_step;
     }
-    if (c->flags & ORC_FLAG_JAIN_BONUS)                             /* dqn.py:434-442 */
-        reward += c->jain_weight * (jains_index(e) - 0.5) / n;
+    if (c->flags & ORC_FLAG_JAIN_BONUS) {                           /* dqn.py:434-442 */
+        int rated;
+        double j = jains_index(e, &rated);
+        if (rated > 0) reward += c->jain_weight * (j - 0.5) / n;    /* `if rates:` -- no bonus before any sensor generated data */
+    }
 
     *reward_out = reward;
     *truncated_out = truncated;
@@ -649,7 +672,9 @@ void orc_normal_pair(uint32_t a, uint32_t b, float* z0, float* z1) {
  *   call 2 (reset, step 0): w0 -> u_fill; w1,w2 -> layout x,y; lane 0's w3 -> curriculum grid choice
  *   (no call 3: the random policy's action of step s is lane 0's w3 of call 0 at step s-1)
  *   call 4 (lane = try):    w0,w1 -> far-start candidate
- *   call 5 (policy steps):  w0,w1 -> (zP, -) in-range sample drawn by a heuristic policy before the step */
+ *   call 5 (policy steps):  w0,w1 -> (zP, -) in-range sample drawn by a heuristic policy before the step
+ *   call 6 (reset, lane 0): w0,w1 -> (zS, -) shadowing sample of the discarded reset observation's ADR update of the
+ *                           OLD sensor 0, which decides the SF the fresh DomainRandEnv sensors inherit (dqn.py:340-351) */
 static void noise_words(uint64_t seed, uint32_t env, uint32_t ep, uint32_t step, uint32_t lane,
                         uint32_t call, uint32_t w[4]) {
     uint32_t ctr[4] = {env, ep, step, lane | (call << 16)};
@@ -678,6 +703,12 @@ void orc_noise_reset_tape(uint64_t seed, uint32_t env, uint32_t ep, int n, float
         tp[0 * n + i] = u24(w[0]);
         noise_words(seed, env, ep, 0, (uint32_t)i, 0, w);
         orc_normal_pair(w[0], w[1], &a, &b); tp[1 * n + i] = a; tp[2 * n + i] = b;
+        tp[3 * n + i] = 0.0f;
+    }
+    {   /* zS: lane 0 of call 6 */
+        uint32_t w[4]; float a, b;
+        noise_words(seed, env, ep, 0, 0u, 6, w);
+        orc_normal_pair(w[0], w[1], &a, &b); tp[3 * n + 0] = a;
     }
 }
 void orc_noise_positions(uint64_t seed, uint32_t env, uint32_t ep, int n, int gw, int gh, float* px, float* py) {
@@ -721,9 +752,10 @@ static void sample_far_start(OrcEnv* e) {
 
 void orc_reset_keyed(OrcEnv* e, float* obs_out) {
     const OrcConfig* c = &e->cfg;
-    float rt[3 * ORC_MAX_SENSORS];
+    float rt[4 * ORC_MAX_SENSORS];
     uint32_t ep = e->episode + 1u;
     orc_noise_reset_tape(c->seed, e->env_index, ep, e->n, rt);
+    const int fresh_sf = inherited_sf(e, (double)rt[3 * e->n + 0]);   /* old sensor 0, old start: before both are replaced */
     if ((c->flags & ORC_FLAG_RANDOM_LAYOUT) && c->num_grid_choices > 0) {   /* dqn.py:334 */
         uint32_t w[4];
         noise_words(c->seed, e->env_index, ep, 0, 0, 2, w);
@@ -732,7 +764,7 @@ void orc_reset_keyed(OrcEnv* e, float* obs_out) {
     }
     if (c->flags & ORC_FLAG_RANDOM_LAYOUT)
         orc_noise_positions(c->seed, e->env_index, ep, e->n, e->grid_w, e->grid_h, e->pos_x, e->pos_y);
-    reset_common(e, rt);
+    reset_common(e, rt, fresh_sf);
     if (c->flags & ORC_FLAG_FAR_START) {
         sample_far_start(e);
         e->uav_x = e->start_x; e->uav_y = e->start_y;               /* dqn.py:364-365 */

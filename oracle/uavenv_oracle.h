@@ -90,7 +90,8 @@ void orc_default_config(OrcConfig* c);
 int  orc_obs_dim(const OrcConfig* c, int n);
 void orc_init(OrcEnv* e, const OrcConfig* c, uint32_t env_index, const float* pos_x, const float* pos_y);
 
-/* Tape-driven entry points.  reset_tape: float[3][n] = (u_fill, zD, zE); step_tape: float[6][n] =
+/* Tape-driven entry points.  reset_tape: float[4][n] = (u_fill, zD, zE, zS -- element 0 only: the sample behind the
+ * SF that fresh DomainRandEnv sensors inherit, dqn.py:340-351; unused without ORC_FLAG_RANDOM_LAYOUT); step_tape: float[6][n] =
  * (zA, zB, u, zC, zD, zE).  Returns 0, or -1 on an invalid action (after ageing the sensors, like
  * the reference: uav_env.py:439-468). */
 void orc_reset_tape(OrcEnv* e, const float* reset_tape, float* obs_out);
@@ -100,7 +101,7 @@ int  orc_step_tape(OrcEnv* e, int action, const float* step_tape, float* obs_out
 /* Keyed entry points: the tape is generated by the counter-based noise specification shared with
  * the HIP kernel (Philox4x32-10 + transcendental-free Box-Muller, DESIGN.md "Noise"). */
 void orc_noise_step_tape(uint64_t seed, uint32_t env_index, uint32_t episode, uint32_t step, int n, float* tape7);
-void orc_noise_reset_tape(uint64_t seed, uint32_t env_index, uint32_t episode, int n, float* tape3);
+void orc_noise_reset_tape(uint64_t seed, uint32_t env_index, uint32_t episode, int n, float* tape4);
 void orc_noise_positions(uint64_t seed, uint32_t env_index, uint32_t episode, int n, int w, int h, float* px, float* py);
 int  orc_noise_action(uint64_t seed, uint32_t env_index, uint32_t episode, uint32_t step);
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

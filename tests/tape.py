@@ -11,8 +11,10 @@ reference draws, per sensor and per step, up to five standard normals and one un
     slot 5  zE  observation in-range check    (iot_sensors.py:215 via uav_env.py:658)
     slot 6  zP  in-range check made by a heuristic policy BEFORE the step (greedy_agents.py:85, :139)
 
-plus, per reset: the buffer pre-fill uniform (uav_env.py:410) and the (zD, zE) pair consumed by
-the observation built inside reset() (uav_env.py:427).
+plus, per reset: the buffer pre-fill uniform (uav_env.py:410), the (zD, zE) pair consumed by
+the observation built inside reset() (uav_env.py:427) and zS (element 0 only): the ADR sample the DISCARDED
+reset observation of DomainRandEnv.reset draws for the old sensor 0, whose SF the fresh sensors inherit
+(dqn.py:340-351).
 
 Every value is produced by 64-bit integer hashing (splitmix64) and is exactly representable in
 float32, so the tape is bit-identical on every machine and never has to be stored in a fixture:
@@ -24,8 +26,8 @@ import numpy as np
 
 SLOT_ZA, SLOT_ZB, SLOT_U, SLOT_ZC, SLOT_ZD, SLOT_ZE, SLOT_ZP = range(7)
 NUM_STEP_SLOTS = 7
-RSLOT_FILL, RSLOT_ZD, RSLOT_ZE = range(3)
-NUM_RESET_SLOTS = 3
+RSLOT_FILL, RSLOT_ZD, RSLOT_ZE, RSLOT_ZS = range(4)
+NUM_RESET_SLOTS = 4
 
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 
@@ -78,7 +80,7 @@ def step_tape(tape_seed, env, step, n):
 
 
 def reset_tape(tape_seed, env, episode, n):
-    """float32[3, n] tape for the reset that opens `episode` of `env`: (u_fill, zD, zE)."""
+    """float32[4, n] tape for the reset that opens `episode` of `env`: (u_fill, zD, zE, zS)."""
     lane = np.arange(n, dtype=np.uint64)
     e = np.full(n, env, dtype=np.uint64)
     ep = np.full(n, episode, dtype=np.uint64)
@@ -86,6 +88,7 @@ def reset_tape(tape_seed, env, episode, n):
     out[RSLOT_FILL] = _uniform_from(_hash(tape_seed, 100, e, ep, lane))
     out[RSLOT_ZD] = _normal_from(_hash(tape_seed, 101, e, ep, lane), _hash(tape_seed, 102, e, ep, lane))
     out[RSLOT_ZE] = _normal_from(_hash(tape_seed, 103, e, ep, lane), _hash(tape_seed, 104, e, ep, lane))
+    out[RSLOT_ZS] = _normal_from(_hash(tape_seed, 105, e, ep, lane), _hash(tape_seed, 106, e, ep, lane))
     return out
 
 

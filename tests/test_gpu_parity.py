@@ -42,7 +42,7 @@ def _tape_tensors(torch, seed, envs, step, n, stride, device):
 
 
 def _reset_tape_tensor(torch, seed, envs, episodes, n, stride, device):
-    rt = np.zeros((len(envs), 3, stride), np.float32)
+    rt = np.zeros((len(envs), T.NUM_RESET_SLOTS, stride), np.float32)
     for k, (e, ep) in enumerate(zip(envs, episodes)):
         rt[k, :, :n] = T.reset_tape(seed, e, ep, n)
     return torch.from_numpy(rt).to(device)
@@ -126,7 +126,7 @@ def test_noise_matches_oracle_bit_for_bit():
             L.orc_noise_step_tape(0x1234ABCD9876, 1000 + k, int(rec["episode"][k]), int(rec["current_step"][k]) + 1, n,
                                   O._fp(want))
             assert np.array_equal(st[k, :, :n], want), (n, k)
-            wr = np.zeros((3, n), np.float32)
+            wr = np.zeros((4, n), np.float32)
             L.orc_noise_reset_tape(0x1234ABCD9876, 1000 + k, int(rec["episode"][k]) + 1, n, O._fp(wr))
             assert np.array_equal(rt[k, :, :n], wr), (n, k)
         env.close()

@@ -42,7 +42,7 @@ def test_tape_is_bit_stable():
     """The fixtures store only `tape_seed`; the tape must never change."""
     h = hashlib.sha256()
     h.update(T.step_tape(424242, 3, 17, 50).tobytes())
-    h.update(T.reset_tape(424242, 3, 2, 50).tobytes())
+    h.update(T.reset_tape(424242, 3, 2, 50)[:3].tobytes())      # rows the reference-made fixtures depend on (row 3 = zS came later)
     px, py = T.positions(424242, 3, 50, 500, 500)
     h.update(px.tobytes()); h.update(py.tobytes())
     h.update(T.actions(424242, 3, 100).tobytes())
