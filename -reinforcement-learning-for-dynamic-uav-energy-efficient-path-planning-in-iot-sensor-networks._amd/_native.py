@@ -17,6 +17,7 @@ FLAG_RANDOM_LAYOUT, FLAG_FAR_START, FLAG_PROX_SHAPING, FLAG_JAIN_BONUS, FLAG_AUT
 
 E_INVALID, E_HIP, E_ACTION, E_ALLOC = -1, -2, -3, -4
 POLICY_ACTIONS, POLICY_RANDOM, POLICY_NEAREST, POLICY_MAX_THROUGHPUT_V2 = 0, 1, 2, 3
+ABI_VERSION = 2
 
 
 class UavEnvConfig(C.Structure):
@@ -117,7 +118,7 @@ def lib():
         "uavenv_step_policy": (C.c_int, [vp, i32, vp, vp, vp, vp, vp, vp, vp]),
         "uavenv_rollout": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
         "uavenv_set_terminal_pool": (C.c_int, [vp, vp, i32, vp, vp]),
-        "uavenv_set_aux_output": (C.c_int, [vp, vp]),
+        "uavenv_set_aux_output": (C.c_int, [vp, vp, i32]),
         "uavenv_attention_weight_floats": (C.c_int, [i32]),
         "uavenv_attention_features": (C.c_int, [vp, vp, vp, i32, i32, vp]),
         "uavenv_frame_stack": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
@@ -131,7 +132,7 @@ def lib():
     for name in EXPORTS:
         fn = getattr(L, name)     # AttributeError if the library does not export a declared symbol
         fn.restype, fn.argtypes = sig[name]
-    if L.uavenv_abi_version() != 1:
+    if L.uavenv_abi_version() != ABI_VERSION:
         raise UavEnvError("libuavenv_hip.so ABI version mismatch")
     _lib = L
     return L

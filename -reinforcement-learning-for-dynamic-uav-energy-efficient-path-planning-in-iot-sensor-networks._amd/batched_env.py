@@ -159,11 +159,15 @@ class BatchedUAVEnv:
                                                 self._p(counter), self._p(index_out)), self._h)
 
     def set_aux_output(self, aux=None):
-        """aux float32 cuda [E, 4] (or [K, E, 4] for rollouts): (action, reward, done, terminal row) per step; None disables."""
+        """aux float32 cuda [E, 4] (or [K, E, 4] for rollouts of up to K steps): (action, reward, done, terminal ticket as
+        int32 bits) per step; None disables."""
+        cap = 0
         if aux is not None:
             assert aux.is_cuda and aux.dtype == torch.float32 and aux.is_contiguous() and aux.shape[-1] == 4
+            cap = aux.numel() // (4 * self.num_envs)
+            assert cap >= 1 and aux.numel() == cap * 4 * self.num_envs, tuple(aux.shape)
         self._aux = aux
-        N.check(self.L.uavenv_set_aux_output(self._h, self._p(aux)), self._h)
+        N.check(self.L.uavenv_set_aux_output(self._h, self._p(aux), cap), self._h)
 
     def dump_noise(self):
         E, G = self.num_envs, self.lane_stride

@@ -30,7 +30,7 @@ struct UavEnv {
     uint8_t* h_done_dev = nullptr; float* h_term_dev = nullptr; uint8_t* h_mask_dev = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float* term_pool = nullptr; uint32_t* term_counter = nullptr; int32_t* term_index = nullptr; int32_t term_rows = 0;
-    float* aux_out = nullptr;
+    float* aux_out = nullptr; int32_t aux_capacity = 0;
     uint32_t* hints = nullptr;      // [2][padded_envs] scheduling hints of the random-policy step (StepArgs::balance)
     int hint_parity = 0;
     bool balance = true;            // UAVENV_NO_BALANCE=1 in the environment keeps the home mapping (A/B timing)
@@ -358,6 +358,8 @@ extern "C" int uavenv_rollout(UavEnv* e, int32_t num_steps, int32_t policy, cons
     if (num_steps <= 0) return fail(e, UAVENV_E_INVALID, "num_steps must be positive");
     if (policy < UAVENV_POLICY_ACTIONS || policy > UAVENV_POLICY_MAX_THROUGHPUT_V2) return fail(e, UAVENV_E_INVALID, "unknown policy");
     if (policy == UAVENV_POLICY_ACTIONS && !actions_dev) return fail(e, UAVENV_E_INVALID, "actions_dev is NULL");
+    if (e->aux_out != nullptr && num_steps > e->aux_capacity)
+        return fail(e, UAVENV_E_INVALID, "rollout of more steps than the attached aux output holds ([K][E][4] blocks): detach it or attach a larger one");
     StepArgs a{actions_dev, actions_out, obs, rew, rew32, done, term, e->num_envs,
                e->term_pool, e->term_counter, nullptr, e->term_rows, policy, e->aux_out, nullptr, nullptr, 0};   // aux [K][E][4] carries the pool rows
     HIP_TRY(e, launch_rollout(e->G, e->padded_envs, e->consts, e->dev_consts, e->ptrs, a, num_steps, (hipStream_t)stream));
@@ -372,9 +374,11 @@ extern "C" int uavenv_set_terminal_pool(UavEnv* e, float* pool_dev, int32_t rows
     return UAVENV_OK;
 }
 
-extern "C" int uavenv_set_aux_output(UavEnv* e, float* aux_out_dev) {
+extern "C" int uavenv_set_aux_output(UavEnv* e, float* aux_out_dev, int32_t capacity_steps) {
     if (!e) return UAVENV_E_INVALID;
-    e->aux_out = aux_out_dev;
+    if (aux_out_dev != nullptr && capacity_steps < 1) return fail(e, UAVENV_E_INVALID, "aux output needs capacity_steps >= 1");
+    if (((uintptr_t)aux_out_dev & 15u) != 0) return fail(e, UAVENV_E_INVALID, "aux output must be 16-byte aligned");
+    e->aux_out = aux_out_dev; e->aux_capacity = aux_out_dev ? capacity_steps : 0;
     return UAVENV_OK;
 }
 

@@ -86,15 +86,16 @@ struct StepArgs {
     uint8_t* done;
     float* term_obs;
     int32_t num_envs;           // E (arrays are padded to a whole number of workgroups)
-    // optional terminal-observation pool (uavenv_set_terminal_pool): terminal rows go to
-    // term_pool[atomicAdd(term_counter, 1) % term_rows] and the row index to term_index[env] (-1 if not done)
+    // optional terminal-observation pool (uavenv_set_terminal_pool): a truncating env takes the ticket
+    // t = atomicAdd(term_counter, 1), writes its terminal row to term_pool[t % term_rows] and the row index to
+    // term_index[env] (-1 if not done); the ticket itself goes into the aux block
     float* term_pool;
     uint32_t* term_counter;
     int32_t* term_index;
     int32_t term_rows;
     int32_t policy;             // UAVENV_POLICY_*
-    float* aux;                 // optional float [E][4] = (action, reward, done, terminal-pool row or -1): the packed
-                                // remainder of a transition block, so that replay insertion needs no pack kernel
+    float* aux;                 // optional [E][4] = (action, reward, done as float; terminal ticket or -1 as int32 bits):
+                                // the packed remainder of a transition block, so that replay insertion needs no pack kernel
     // SIMD load balancing (a pure scheduling hint: any value gives the same results).  balance != 0: the wavefronts of
     // a workgroup take its environments collect-actions-first, so collect steps (1.6x the work of a move) spread evenly
     // over the CU's SIMDs.  The "is a collect" bits come from `actions`, or for the in-kernel random policy from

@@ -1007,7 +1007,7 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
     // ---- observation of the stepped state (side effect: ADR EMA) -------------------------------
     const bool auto_reset = (UAV_FLAGS(c) & UAVENV_FLAG_AUTO_RESET) != 0;
     const bool do_reset = truncated & auto_reset;
-    int term_row = -1;
+    int term_ticket = -1;         // value of the terminal-pool counter when this step claimed its row (row = ticket mod rows)
     {
         float* dst = nullptr;
         if (in_batch) {
@@ -1018,12 +1018,15 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
             int row = -1;
             if (__any(do_reset & in_batch)) {
                 uint32_t t = 0u;
-                if (do_reset & in_batch & (gl == 0)) t = atomicAdd(a.term_counter, 1u) % (uint32_t)a.term_rows;
+                if (do_reset & in_batch & (gl == 0)) t = atomicAdd(a.term_counter, 1u);
                 t = gshfl<G>(t, 0);
-                if (do_reset & in_batch) { row = (int)t; dst = a.term_pool + (size_t)t * (size_t)c.obs_dim; }
+                if (do_reset & in_batch) {
+                    term_ticket = (int)(t & 0x7FFFFFFFu);
+                    row = (int)(t % (uint32_t)a.term_rows);
+                    dst = a.term_pool + (size_t)row * (size_t)c.obs_dim;
+                }
             }
             if (in_batch && gl == 0 && a.term_index != nullptr) a.term_index[out] = row;
-            term_row = row;
         }
         observe<G, kLean>(c, s, n, e.gw, e.gh, e.inv_w, e.inv_h, e.ux, e.uy, e.battery, act, true, det, z.zD, z.zE, dst);   // :488
     }
@@ -1072,7 +1075,7 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
         if (a.reward32) a.reward32[out] = (float)reward;
         if (a.done) a.done[out] = truncated ? 1 : 0;
         if (a.aux) reinterpret_cast<float4*>(a.aux)[out] = make_float4((float)action, (float)reward, truncated ? 1.0f : 0.0f,
-                                                                    (float)term_row);
+                                                                    __int_as_float(term_ticket));
     }
 
     // ---- SB3 VecEnv auto-reset: episode stats, reset, first observation of the new episode -----------

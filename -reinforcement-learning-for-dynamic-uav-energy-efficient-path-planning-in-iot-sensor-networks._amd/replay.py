@@ -1,64 +1,104 @@
 """Shared replay ring fed by an all-gather of transition blocks (BASELINE config 4).
 
 One process per GPU owns a shard of environments.  Each vector step produces, per rank, ONE contiguous
-transition block   [ obs: E x D float32 | aux: E x 4 float32 = (action, reward, done, terminal row) ].
+transition block   [ obs: E x D float32 | aux: E x 4 = (action, reward, done, terminal ticket) ].
 The step kernel writes both parts DIRECTLY into this rank's block of the current ring slot
 (`local_obs_slot()` / `local_aux_slot()`, uavenv_set_aux_output), so inserting into the replay buffer
 costs no copy and no pack kernel; the other ranks' blocks arrive through one in-place
-`all_gather_into_tensor` per step (RCCL over xGMI when the backend is "nccl"; "gloo" on CPU for the
-multi-process tests), issued on a side stream so that it overlaps the next environment step.
+`all_gather_into_tensor` per chunk of L slots (RCCL over xGMI when the backend is "nccl"; "gloo" on CPU for
+the multi-process tests), issued on a side stream so that it overlaps the following environment steps.
 
-next_obs is not stored: it is the following slot's obs, except where `done` (the env was auto-reset,
-so the following slot holds the first observation of the NEXT episode): there the terminal observation
-is looked up in a compact pool that the step kernel fills directly (uavenv_set_terminal_pool; SB3's
-"terminal_observation" semantics, `terminated` is always False in this environment so every episode end
-bootstraps from its terminal observation).  The pool is local to a rank: transitions of other ranks that
-end an episode are returned with valid=False (about 1 in 1500) and must be masked out of the loss.
+next_obs is not stored: it is the following slot's obs, except where `done` (the env was auto-reset, so the
+following slot holds the first observation of the NEXT episode).  There the step kernel has written the
+TERMINAL observation (SB3's "terminal_observation"; `terminated` is always False in this environment, so every
+episode end bootstraps from it) into the TERMINAL SECTION of the same chunk: every (chunk, rank) part of the
+ring is
+
+    [ L transition blocks | T terminal rows of D floats | count ]
+
+and travels as a whole in the chunk's collective, so an episode end is a valid transition on EVERY rank -- these
+are exactly the transitions that carry the -5000 * unvisited / -1000 * starved terminal penalties
+(reward_function.py:59-67).  A terminal row is addressed by its ticket = the value of the chunk's counter when
+the kernel claimed it (row = ticket mod T; `count` = the counter's final value travels with the section): a
+row has been overwritten by a later episode end of the same chunk iff count - ticket > T, which `_next_frame`
+reports as valid = False instead of handing out another environment's observation.  T defaults to E: every
+environment of the shard can end inside one chunk (they all start together: with the base configuration all
+environments truncate within ~60 steps of each other) without losing a row.
 """
 import torch
 import torch.distributed as dist
+
+
+def _pad4(n):
+    return (int(n) + 3) & ~3
 
 
 class TransitionRing:
     def __init__(self, capacity, envs_per_rank, obs_dim, device, world_size=1, rank=0, group=None, terminal_rows=None,
                  chunk_len=1, always_exchange=False):
         """chunk_len: slots per exchange.  1 = every commit() all-gathers its slot in place.  L > 1 = the ring is
-        split into capacity/L chunks and a chunk is gathered (one in-place collective of L blocks per rank) when its last
-        slot is committed: L times fewer, L times larger collectives -- at ~10 us per step the per-call host cost of a
-        collective is several steps long -- and the natural unit for HIP-graph replay (`capture_chunks`)."""
+        split into capacity/L chunks and a chunk is gathered (one in-place collective of L blocks + the terminal
+        section per rank) when its last slot is committed: L times fewer, L times larger collectives -- at ~10 us
+        per step the per-call host cost of a collective is several steps long -- and the natural unit for HIP-graph
+        replay (`capture_chunks`).  terminal_rows: T, terminal rows per (chunk, rank); default E (see above).
+
+        A chunk is recycled as a whole: once the head enters it, its older slots stop being sampled (their terminal
+        rows are about to be overwritten), so the ring holds between capacity - L and capacity - 1 slots."""
         self.capacity, self.E, self.D = int(capacity), int(envs_per_rank), int(obs_dim)
         self.L = int(chunk_len)
         assert self.L >= 1 and self.capacity % self.L == 0
         self.n_chunks = self.capacity // self.L
+        assert self.n_chunks >= 2 or self.L == 1, "a chunked ring needs at least two chunks"
         self.world, self.rank, self.group = int(world_size), int(rank), group
         self.exchange = self.world > 1 or bool(always_exchange)   # always_exchange: run the collective even alone (self-test)
         self.device = torch.device(device)
-        # [chunk][rank][slot in chunk][block]: a rank's part of a chunk (L blocks, each obs then aux) is contiguous and
-        # the chunk is the concatenation of the ranks' parts => ONE in-place all-gather per chunk
-        self.block = self.E * (self.D + 4)
-        self.store = torch.zeros(self.n_chunks, self.world, self.L, self.block, dtype=torch.float32, device=self.device)
-        self._obs5 = self.store[..., :self.E * self.D].view(self.n_chunks, self.world, self.L, self.E, self.D)
-        self._aux5 = self.store[..., self.E * self.D:].view(self.n_chunks, self.world, self.L, self.E, 4)
+        self.T = int(terminal_rows) if terminal_rows is not None else self.E
+        assert self.T >= 1
+        # [chunk][rank][ L blocks | terminal rows | count ]: a rank's part of a chunk is contiguous and the chunk is the
+        # concatenation of the ranks' parts => ONE in-place all-gather per chunk.  Every piece starts 16-byte aligned
+        # (the kernel stores aux rows as float4).
+        self.obs_floats = _pad4(self.E * self.D)
+        self.block = self.obs_floats + self.E * 4
+        self.term_off = self.L * self.block
+        self.count_off = self.term_off + _pad4(self.T * self.D)
+        self.section = self.count_off + 4
+        self.store = torch.zeros(self.n_chunks, self.world, self.section, dtype=torch.float32, device=self.device)
+        blocks = self.store[..., :self.term_off].view(self.n_chunks, self.world, self.L, self.block)
+        self._obs5 = blocks[..., :self.E * self.D].view(self.n_chunks, self.world, self.L, self.E, self.D)
+        self._aux5 = blocks[..., self.obs_floats:].view(self.n_chunks, self.world, self.L, self.E, 4)
+        self._term4 = self.store[..., self.term_off:self.term_off + self.T * self.D].view(self.n_chunks, self.world, self.T, self.D)
+        self._i32 = self.store.view(torch.int32)
+        self._count = self._i32[..., self.count_off]                      # [chunk][rank]
+        self._ticket5 = self._i32[..., :self.term_off].view(self.n_chunks, self.world, self.L, self.block)[..., self.obs_floats:] \
+            .view(self.n_chunks, self.world, self.L, self.E, 4)[..., 3]  # aux word 3 as the int32 it is
         if self.L == 1:      # the plain [slot][rank][env] views
-            self.obs = self._obs5.view(self.capacity, self.world, self.E, self.D)
-            self.aux = self._aux5.view(self.capacity, self.world, self.E, 4)
-        # terminal-observation pool (rows recycle; sized so that a row outlives the ring slot that refers to it:
-        # ~E/1400 episodes end per step)
-        self.terminal_rows = int(terminal_rows) if terminal_rows is not None else max(1024, (self.capacity * self.E) // 256)
-        self.term_pool = torch.zeros(self.terminal_rows, self.D, dtype=torch.float32, device=self.device)
-        self.term_counter = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self.obs = self._obs5.squeeze(2)
+            self.aux = self._aux5.squeeze(2)
         self._env = None
         self.head = 0                 # next slot to write
-        self.size = 0                 # number of valid slots
+        self.size = 0                 # number of sampleable slots behind the head
         self._pending = [None] * self.n_chunks     # outstanding collective per chunk
         self._comm_stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
 
+    # ---- the terminal section of a chunk ---------------------------------------------------------------
+    def local_terminal_section(self, chunk=None):
+        """(rows [T, D], counter int32 [1]) of THIS rank's terminal section of a chunk: what
+        BatchedUAVEnv.set_terminal_pool takes."""
+        c = self.head // self.L if chunk is None else int(chunk)
+        return self._term4[c, self.rank], self._i32[c, self.rank, self.count_off:self.count_off + 1]
+
+    def _point_env(self, slot=None):
+        """Aim the attached environment's aux / terminal outputs at a slot (default: the head)."""
+        slot = self.head if slot is None else slot
+        pool, counter = self.local_terminal_section(slot // self.L)
+        self._env.set_terminal_pool(pool, counter, None)
+        self._env.set_aux_output(self.local_aux_slot(slot))
+
     def attach(self, env):
-        """Let `env` (BatchedUAVEnv) write terminal observations into this ring's pool and the (action, reward,
-        done, terminal row) part of every transition straight into the ring."""
-        env.set_terminal_pool(self.term_pool, self.term_counter, None)
+        """Let `env` (BatchedUAVEnv) write terminal observations into the head chunk's terminal section and the
+        (action, reward, done, terminal ticket) part of every transition straight into the ring."""
         self._env = env
-        env.set_aux_output(self.local_aux_slot())
+        self._point_env()
 
     # ---- producer side -----------------------------------------------------------------------
     def _cj(self, slot):
@@ -70,6 +110,14 @@ class TransitionRing:
 
     def aux_at(self, slot, r, e):
         return self._aux5[slot // self.L, r, slot % self.L, e]
+
+    def tickets_at(self, slot, r, e):
+        """Terminal tickets (int32; -1 where the step into `slot` did not end an episode)."""
+        return self._ticket5[slot // self.L, r, slot % self.L, e]
+
+    def terminal_at(self, slot, r, ticket):
+        """Terminal observation rows of the chunk holding `slot` for tickets of that chunk (row = ticket mod T)."""
+        return self._term4[slot // self.L, r, ticket % self.T]
 
     def local_obs_slot(self, slot=None):
         """[E, D] view of THIS rank's part of a slot: pass it as `obs_out` to BatchedUAVEnv.step*()."""
@@ -90,7 +138,7 @@ class TransitionRing:
         self.wait_chunk(slot // self.L)
 
     def _gather_chunk(self, c):
-        """One in-place all-gather of this rank's L blocks of chunk c (RCCL on a side stream / gloo on CPU)."""
+        """One in-place all-gather of this rank's part of chunk c (RCCL on a side stream / gloo on CPU)."""
         out, inp = self.store[c].view(-1), self.store[c, self.rank].view(-1)
         if self._comm_stream is not None:
             self._comm_stream.wait_stream(torch.cuda.current_stream(self.device))
@@ -100,40 +148,57 @@ class TransitionRing:
             w = dist.all_gather_into_tensor(out, inp.clone(), group=self.group, async_op=True)
         self._pending[c] = w
 
-    def _advance(self, n):
-        """Move the head by n committed slots; gather every chunk that was completed; make sure the chunk the head
-        enters next is no longer being gathered."""
+    def _advance(self, n, zero_counts=True):
+        """Move the head by n committed slots; gather every chunk that was completed; recycle the chunk the head
+        enters (its previous gather must be over, its terminal counter restarts at 0, its old slots leave the
+        sampling window)."""
         for _ in range(n):
             slot = self.head
             c, j = self._cj(slot)
             if self.exchange and j == self.L - 1:
                 self._gather_chunk(c)
             self.head = (slot + 1) % self.capacity
-            self.size = min(self.size + 1, self.capacity)
+            if self.head % self.L == 0:
+                nc = self.head // self.L
+                self.wait_chunk(nc)
+                if zero_counts:
+                    self._count[nc, self.rank] = 0
+            self.size = min(self.size + 1, self.capacity - self.L + self.head % self.L)
         self.wait_slot(self.head)
 
-    def commit(self, actions=None, reward=None, done=None):
+    def commit(self, actions=None, reward=None, done=None, terminal_obs=None):
         """Publish this rank's block of the current slot.  With an attached env the kernel has already written
-        the aux part; otherwise (tests, foreign producers) pass actions / reward / done to fill it here."""
+        the aux part and the terminal rows; otherwise (tests, foreign producers) pass actions / reward / done
+        (and terminal_obs [E, D] for the rows where done) to fill them here the way the kernel does."""
         slot = self.head
         if actions is not None:
+            c, j = self._cj(slot)
             aux = self.local_aux_slot(slot)
             aux[:, 0] = actions.to(torch.float32)
             aux[:, 1] = reward.to(torch.float32)
             aux[:, 2] = done.to(torch.float32)
-            aux[:, 3] = -1.0
+            tick = self._ticket5[c, self.rank, j]
+            tick.fill_(-1)
+            if terminal_obs is not None:
+                idx = torch.nonzero(done.to(torch.bool)).flatten()
+                if idx.numel():
+                    base = int(self._count[c, self.rank])
+                    t = base + torch.arange(idx.numel(), device=self.device)
+                    tick[idx] = t.to(torch.int32)
+                    self._term4[c, self.rank, t % self.T] = terminal_obs[idx].to(torch.float32)
+                    self._count[c, self.rank] = base + idx.numel()
         self._advance(1)
         if self._env is not None:
-            self._env.set_aux_output(self.local_aux_slot())
+            self._point_env()
         return slot
 
     # ---- launch-bound producer loops: one HIP graph per chunk -----------------------------------------------
     def capture_chunks(self, step_fn):
-        """Capture, for every chunk, its L consecutive `step_fn(obs_slot); (aux re-pointing)` launches into one HIP graph
-        (the head must stand at the start of a chunk).  `replay_chunk(graphs)` then costs one graph launch (plus the
-        chunk's collective when ranks share the ring, issued from the host after the replay) instead of L Python ->
-        ctypes -> hipLaunchKernel round trips of ~12 us each -- more than the step kernel itself at 4096 environments.
-        `step_fn(obs_out)` must only enqueue work on the current stream (e.g. `env.step_random`)."""
+        """Capture, for every chunk, "restart the terminal counter; L x (re-point outputs, `step_fn(obs_slot)`)" into one
+        HIP graph (the head must stand at the start of a chunk).  `replay_chunk(graphs)` then costs one graph launch
+        (plus the chunk's collective when ranks share the ring, issued from the host after the replay) instead of L
+        Python -> ctypes -> hipLaunchKernel round trips of ~12 us each -- more than the step kernel itself at 4096
+        environments.  `step_fn(obs_out)` must only enqueue work on the current stream (e.g. `env.step_random`)."""
         assert self.device.type == "cuda" and self._env is not None and self.head % self.L == 0
         self.drain()
         torch.cuda.synchronize(self.device)
@@ -142,12 +207,13 @@ class TransitionRing:
             c = (head0 // self.L + k) % self.n_chunks
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
+                self._count[c, self.rank].zero_()
                 for j in range(self.L):
                     slot = c * self.L + j
-                    self._env.set_aux_output(self.local_aux_slot(slot))
+                    self._point_env(slot)
                     step_fn(self.local_obs_slot(slot))
             graphs[c] = g
-        self._env.set_aux_output(self.local_aux_slot())          # capturing executed nothing
+        self._point_env()          # capturing executed nothing
         return graphs
 
     def replay_chunk(self, graphs):
@@ -156,8 +222,8 @@ class TransitionRing:
         assert self.head % self.L == 0
         self.wait_chunk(c)            # its previous gather (a full revolution ago) must be done before it is overwritten;
         graphs[c].replay()            # the gather of the chunk just before this one keeps running on the side stream
-        self._advance(self.L)
-        self._env.set_aux_output(self.local_aux_slot())
+        self._advance(self.L, zero_counts=False)      # the next chunk's graph restarts its own counter
+        self._point_env()
 
     def drain(self):
         for c in range(self.n_chunks):
@@ -166,29 +232,39 @@ class TransitionRing:
             torch.cuda.current_stream(self.device).wait_stream(self._comm_stream)
 
     # ---- consumer side -----------------------------------------------------------------------
+    def sampleable(self):
+        """Slots behind the head that can be sampled on this rank: all committed ones, minus -- when ranks share a
+        chunked ring -- those of the head chunk, whose other-rank parts have not been gathered yet."""
+        return self.size - (self.head % self.L if (self.exchange and self.L > 1) else 0)
+
     def _draw(self, batch_size, generator):
-        n_slots = self.size - 1
+        n = self.sampleable()
+        skip = self.size - n                       # committed but not yet visible slots right behind the head
         oldest = (self.head - self.size) % self.capacity
-        j = torch.randint(0, n_slots, (batch_size,), generator=generator, device=self.device)
+        j = torch.randint(0, n - 1, (batch_size,), generator=generator, device=self.device)
         r = torch.randint(0, self.world, (batch_size,), generator=generator, device=self.device)
         e = torch.randint(0, self.E, (batch_size,), generator=generator, device=self.device)
+        assert skip >= 0
         return j, (oldest + j) % self.capacity, r, e
 
     def _next_frame(self, slot, r, e):
         """(action, reward, done, newest frame of next_obs, valid) of the transitions slot -> slot+1."""
         nxt = (slot + 1) % self.capacity
-        aux = self.aux_at(nxt, r, e)               # the aux row stored WITH an observation describes the step INTO it
+        c, j = nxt // self.L, nxt % self.L
+        aux = self._aux5[c, r, j, e]               # the aux row stored WITH an observation describes the step INTO it
         done = aux[:, 2] > 0.5
-        tidx = aux[:, 3].long()
-        have_term = done & (tidx >= 0) & (r == self.rank)
-        last = torch.where(have_term.unsqueeze(1), self.term_pool[tidx.clamp(min=0)], self.obs_at(nxt, r, e))
+        ticket = self._ticket5[c, r, j, e].long()
+        count = self._count[c, r].long()
+        have_term = done & (ticket >= 0) & (count - ticket <= self.T)      # the row has not been overwritten since
+        row = ticket.clamp(min=0) % self.T
+        last = torch.where(have_term.unsqueeze(1), self._term4[c, r, row], self._obs5[c, r, j, e])
         return aux[:, 0].long(), aux[:, 1], done, last, ~done | have_term
 
     def sample(self, batch_size, generator=None):
         """Uniform sample of transitions (obs, action, reward, done, next_obs, valid) over all ranks' envs.
         Slot s holds the observation s_t together with (a, r, done) of the step that PRODUCED it, so the
         transition out of slot s reads its action / reward / done from slot s+1."""
-        assert self.size >= 2
+        assert self.sampleable() >= 2
         self.drain()
         _, slot, r, e = self._draw(batch_size, generator)
         action, reward, done, last, valid = self._next_frame(slot, r, e)
@@ -199,7 +275,7 @@ class TransitionRing:
         fly (SB3 VecFrameStack layout: [oldest | ... | newest], frames from before the episode start zeroed),
         so the replay stores each frame ONCE instead of n_stack times (dqn.py:1085 budgets 2 x 612 floats per
         transition for the stacked copies)."""
-        assert self.size >= n_stack + 1
+        assert self.sampleable() >= 2
         self.drain()
         k = int(n_stack)
         j, slot, r, e = self._draw(batch_size, generator)

@@ -86,10 +86,16 @@ def latest_traffic(workload_key):
         try:
             d = json.load(open(p))
             if d.get("workload") == workload_key:
-                best = d
+                best = dict(d, file=os.path.relpath(p, ROOT))
         except Exception:
             pass
     return best
+
+
+def build_commit():
+    """The commit tools/gpu.sh stamped into the tree (the GPU box has no .git), or None."""
+    p = os.path.join(ROOT, ".build_commit")
+    return open(p).read().strip() if os.path.exists(p) else None
 
 
 def latest_valu_per_wave():
@@ -119,6 +125,7 @@ def main():
     ap.add_argument("--ring", type=int, default=128, help="replay-ring slots used by the bench (two chunks = two HIP graphs / collectives)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of replaying HIP graphs")
+    ap.add_argument("--repeats", type=int, default=0, help="timed regions of K steps each (median reported); 0 = as many as ~1500 steps need, at most 15")
     ap.add_argument("--fused", type=int, default=16, help="steps per launch of the additional fused-rollout measurement (0 = skip)")
     args = ap.parse_args()
 
@@ -152,12 +159,17 @@ def main():
     if not distributed:
         exchange = "none"
     use_graph = not args.no_graph
-    # slots per chunk = steps per HIP graph = steps per collective: half the ring, but short runs get shorter chunks
-    # so that most of their steps are still replayed rather than launched one by one
+    # slots per chunk = steps per HIP graph = steps per collective.  The chunk length is chosen so that the K timed steps
+    # are whole graph replays: K itself when it fits half the ring (a short run is ONE replay), else the largest divisor
+    # of K in 16..ring/2, else ring/2 with the remainder launched step by step.
+    half = max(1, args.ring // 2)
     L = 1
     if use_graph:
-        while 2 * L <= min(max(1, args.ring // 2), max(1, K // 4)):
-            L *= 2
+        if K <= half:
+            L = K
+        else:
+            divs = [d for d in range(16, half + 1) if K % d == 0]
+            L = max(divs) if divs else half
     ring_slots = 2 * L if use_graph else args.ring
 
     def make_ring(shared):
@@ -216,21 +228,37 @@ def main():
 
     run_steps(W, align=True)
     ring.drain()
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()                       # torch's current stream IS the stream the kernel is launched on
-    run_steps(K)
-    t_enq = time.perf_counter() - t0
-    ev1.record()
-    ring.drain()
-    barrier()
-    dt = time.perf_counter() - t0
-    ev_ms = ev0.elapsed_time(ev1)
-    if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+
+    def timed_region():
+        """EXACTLY K steps between two barrier + synchronize brackets; returns (wall s, enqueue s, device-event ms)."""
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()                       # torch's current stream IS the stream the kernel is launched on
+        run_steps(K)
+        t_enq = time.perf_counter() - t0
+        ev1.record()
+        ring.drain()
+        while not ev1.query():             # poll instead of sleeping in the driver: the wake-up latency of a blocking
+            pass                           # wait (10-20 us) is host noise of the order of a step
+        barrier()
+        dt_ = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([dt_], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_ = float(t.item())
+        return dt_, t_enq, ev0.elapsed_time(ev1)
+
+    # A region of a few dozen steps lasts a fraction of a millisecond, where one scheduling hiccup of the host moves the
+    # figure by 10 %: short regions are REPEATED (each one exactly K steps in its own brackets, re-aligned to a chunk
+    # boundary in between, untimed) and the MEDIAN region is reported, with the spread beside it.
+    repeats = args.repeats if args.repeats > 0 else max(1, min(15, -(-1500 // K)) | 1)
+    regions = []
+    for _ in range(repeats):
+        regions.append(timed_region())
+        run_steps(0, align=True)
+    regions.sort(key=lambda x: x[0])
+    dt, t_enq, ev_ms = regions[len(regions) // 2]
 
     # Kernel-only launch duration, HIP events on the launch stream around back-to-back launches
     # (measured on every rank, after the timed region so it cannot perturb it)
@@ -261,7 +289,10 @@ def main():
     fused = None
     if args.fused > 0 and exchange == "none":
         F = args.fused
-        launches = max(1, min(K, 1600) // F)
+        launches = max(20, min(K, 1600) // F)
+        ring.drain()
+        env.set_aux_output(None)           # the ring's aux slot holds ONE [E][4] block, a rollout writes F of them
+        env.set_terminal_pool(None, None, None)
         slab = torch.empty(F, E, env.obs_dim, dtype=torch.float32, device=dev)
         for _ in range(3):
             env.rollout(F, obs_out=slab)
@@ -289,6 +320,8 @@ def main():
         "metric": "env-steps/sec at 4096 envs\u00d750 sensors, 1/2/4/8 MI355X; HBM GB/s vs peak",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "timed_regions": {"repeats": repeats, "reported": "median", "steps_each": K,
+                          "ms_per_step_min": regions[0][0] / K * 1e3, "ms_per_step_max": regions[-1][0] / K * 1e3},
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{E} envs/GPU x {n} sensors, {args.grid}x{args.grid} grid, BASE_ENV_CONFIG, "
                                f"uniform-random policy (in-kernel Philox), auto-reset, obs+reward+done written every step",
@@ -303,6 +336,11 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": (tr or {}).get("hbm_bytes_per_launch"),
+                     # the PMC passes are separate profiler runs (tools/profile_bench.sh): say which code they measured
+                     "traffic_source": None if tr is None else {"file": tr.get("file"), "measured_on_commit": tr.get("commit"),
+                                                                "this_run_commit": build_commit()},
+                     "achieved_from_traffic": None if not (tr or {}).get("hbm_bytes_per_launch") else
+                     tr["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9,
                      "kernel": "uav_step_kernel<64, true>", "algorithmic_bytes_per_launch": per_launch_bytes,
                      "algorithmic_bytes_per_env_step": B, "avg_launch_ms": kern_ms,
                      "timed_region_event_ms_per_step": ev_ms / K,
@@ -323,6 +361,7 @@ def main():
         out["config"]["exchange_error"] = exchange_error
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n, (args.grid, args.grid))
+        out["cpu_baseline"]["cores_available"] = os.cpu_count()
         out["cpu_baseline"]["host"] = {"cpu_count": os.cpu_count()}
     elif rank == 0:
         out["cpu_baseline"] = None

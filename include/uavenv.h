@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define UAVENV_ABI_VERSION 1
+#define UAVENV_ABI_VERSION 2
 
 /* error codes */
 #define UAVENV_OK              0
@@ -226,16 +226,21 @@ int uavenv_rollout(UavEnv* env, int32_t num_steps, int32_t policy, const int32_t
 
 /* Optional compact pool for terminal observations (replay buffers need next_obs = terminal observation on
  * truncated transitions, SB3 "terminal_observation"; ~1 in 1500 steps per env truncates).  When set, a
- * truncating env writes its terminal row to pool_dev[atomicAdd(*counter_dev, 1) % rows][obs_dim] instead of
- * terminal_obs_dev[env], and index_out_dev[env] (int32 [E], nullable) receives that row or -1.
- * pool_dev == NULL restores the per-env terminal_obs_dev rows. */
+ * truncating env takes the ticket t = atomicAdd(*counter_dev, 1) and writes its terminal row to
+ * pool_dev[t % rows][obs_dim] instead of terminal_obs_dev[env]; index_out_dev[env] (int32 [E], nullable) receives
+ * that row or -1, and the aux block (below) the ticket itself.  Rows recycle: the row of ticket t is intact while
+ * *counter_dev - t <= rows, which lets a consumer DETECT an overwritten row instead of reading another environment's
+ * observation.  The caller may move the pool / restart the counter between launches (e.g. one pool section per
+ * replay-ring chunk).  pool_dev == NULL restores the per-env terminal_obs_dev rows. */
 int uavenv_set_terminal_pool(UavEnv* env, float* pool_dev, int32_t rows, uint32_t* counter_dev, int32_t* index_out_dev);
 
 /* Optional packed remainder of the transition block: when set, every step also writes
- * aux_out_dev float [E][4] = (action, reward, done, terminal-pool row or -1) -- with obs_out_dev this is the whole
- * (obs, action, reward, done) transition, so inserting into a replay buffer needs no extra pack kernel and the
- * multi-GPU exchange is one all-gather of one contiguous block.  (uavenv_rollout: [K][E][4].)  NULL disables. */
-int uavenv_set_aux_output(UavEnv* env, float* aux_out_dev);
+ * aux_out_dev [E][4] = (action, reward, done as float32; the terminal-pool ticket, or -1, as int32 bits) -- with
+ * obs_out_dev this is the whole (obs, action, reward, done) transition, so inserting into a replay buffer needs no
+ * extra pack kernel and the multi-GPU exchange is one all-gather of one contiguous block.  capacity_steps = how many
+ * [E][4] blocks the buffer holds: uavenv_rollout writes [K][E][4] and refuses K > capacity_steps (UAVENV_E_INVALID)
+ * instead of running past the buffer.  NULL disables. */
+int uavenv_set_aux_output(UavEnv* env, float* aux_out_dev, int32_t capacity_steps);
 
 /* ---- frame stack (the caller directly above the path in the trainer: dqn.py:1278) ------------------ */
 /* replaces: SB3 VecFrameStack(n_stack=k).step_wait on device, in place.  stacked_dev float [E][k*obs_dim]

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/uavenv.h but not exported"
     assert sorted(N.EXPORTS) == declared, "python binding and header disagree on the entry points"
-    assert N.lib().uavenv_abi_version() == 1
+    assert N.lib().uavenv_abi_version() == N.ABI_VERSION == 2
 
 
 def test_struct_mirrors_match_the_header():

@@ -217,27 +217,69 @@ def test_replay_ring_with_terminal_pool():
     kw = dict(num_sensors=20, max_steps=13, duty_cycle=70.0, grid_size=(90, 90), seed=8)
     env = U.BatchedUAVEnv(E, **kw)
     want = O.trace_keyed(O.default_config(**kw), E, steps)
-    ring = U.TransitionRing(steps + 1, E, env.obs_dim, env.device)
+    ring = U.TransitionRing(steps + 2, E, env.obs_dim, env.device)
     ring.attach(env)
     env.reset(); ring.local_obs_slot().copy_(env.obs)
     ring.commit(torch.zeros(E, device=env.device), torch.zeros(E, device=env.device), torch.zeros(E, device=env.device))
     for s in range(steps):
         env.step_random(obs_out=ring.local_obs_slot())
-        ring.commit()                                  # the kernel wrote (action, reward, done, pool row) itself
+        ring.commit()                                  # the kernel wrote (action, reward, done, terminal ticket) itself
     torch.cuda.synchronize()
     # slot s+1 holds obs after step s together with (action, reward, done) OF step s
-    obs = ring.obs[:, 0].cpu().numpy(); aux = ring.aux[:, 0].cpu().numpy(); pool = ring.term_pool.cpu().numpy()
+    obs = ring.obs[:, 0].cpu().numpy(); aux = ring.aux[:, 0].cpu().numpy()
+    all_e = torch.arange(E, device=env.device)
     assert np.array_equal(obs[0], want["reset_obs"])
     n_term = 0
     for s in range(steps):
         assert np.array_equal(obs[s + 1], want["obs"][s])
         assert np.array_equal(aux[s + 1, :, 0].astype(np.int32), want["actions"][s])
         assert np.array_equal(aux[s + 1, :, 2] > 0.5, want["done"][s].astype(bool))
+        tick = ring.tickets_at(s + 1, 0, all_e)
+        rows = ring.terminal_at(s + 1, 0, tick.clamp(min=0).long()).cpu().numpy()
+        tick = tick.cpu().numpy()
         for k in np.nonzero(want["done"][s])[0]:
-            row = int(aux[s + 1, k, 3]); assert row >= 0
-            assert np.array_equal(pool[row], want["term_obs"][s, k]); n_term += 1
-        assert np.all(aux[s + 1, ~want["done"][s].astype(bool), 3] == -1)
+            assert tick[k] >= 0
+            assert np.array_equal(rows[k], want["term_obs"][s, k]); n_term += 1
+        assert np.all(tick[~want["done"][s].astype(bool)] == -1)
     assert n_term >= E * 3
+    # and through the sampler: every episode end is a valid transition whose next_obs is its terminal observation
+    b = ring.sample(4096, generator=torch.Generator(device=env.device).manual_seed(1))
+    assert b["valid"].all() and b["done"].any()
+    env.close()
+
+
+@pytest.mark.parametrize("L", [1, 8])
+def test_replay_ring_all_envs_end_on_the_same_step(L):
+    """Step-limit episodes end for EVERY environment on the same step (a pool sized for the average rate of
+    episode ends hands out overwritten rows).  Terminal sections hold E rows per chunk, so no row is lost with one
+    burst per chunk -- and when a chunk sees more episode ends than rows, the overwritten ones come back valid=False,
+    never as another environment's observation."""
+    torch, U, O = _mods()
+    E = 1500                                            # more than the old default pool of 1024 rows
+    kw = dict(num_sensors=10, max_steps=7, grid_size=(60, 60), seed=4)
+    env = U.BatchedUAVEnv(E, **kw)
+    D = env.obs_dim
+    ring = U.TransitionRing(32, E, D, env.device, chunk_len=L); ring.attach(env)
+    obs = env.reset(); ring.local_obs_slot().copy_(obs)
+    z = torch.zeros(E, device=env.device); ring.commit(z, z, z)
+    per_step = [None]
+    for s in range(27):
+        o, r, d = env.step_random(obs_out=ring.local_obs_slot())
+        slot = ring.commit()
+        per_step.append((slot, d.clone()))
+    torch.cuda.synchronize()
+    assert all(bool(d.all()) == ((s % 7) == 0) for s, (slot, d) in enumerate(per_step[1:], 1))   # all end together, every 7th step
+    b = ring.sample(20000, generator=torch.Generator(device=env.device).manual_seed(2))
+    done = b["done"]
+    assert done.any()
+    if L == 1:                                          # one burst per chunk: nothing lost
+        assert b["valid"].all()
+    else:                                               # a chunk of 8 slots can hold two bursts of E: the first is overwritten
+        assert (~b["valid"]).any() and b["valid"][done].any()
+    # every valid terminal transition carries ITS OWN environment's terminal observation: header = position / battery of a
+    # UAV that has flown 7 steps, never the (0, 0, 1) header of a freshly reset one
+    nxt = b["next_obs"][done & b["valid"]]
+    assert (nxt[:, 2] < 1.0).all()
     env.close()
 
 
@@ -247,7 +289,7 @@ def test_stacked_sampling_equals_frame_stack():
     E, steps, k = 24, 50, 4
     env = U.BatchedUAVEnv(E, num_sensors=10, max_steps=11, seed=3)
     D = env.obs_dim
-    ring = U.TransitionRing(steps + 1, E, D, env.device); ring.attach(env)
+    ring = U.TransitionRing(steps + 2, E, D, env.device); ring.attach(env)
     fs = U.FrameStack(E, D, k, env.device)
     obs = env.reset(); ring.local_obs_slot().copy_(obs)
     z = torch.zeros(E, device=env.device); ring.commit(z, z, z)
@@ -255,12 +297,14 @@ def test_stacked_sampling_equals_frame_stack():
     for s in range(steps):
         o, r, d = env.step_random(obs_out=ring.local_obs_slot())
         ring.commit()
-        # (with the pool attached the kernel writes terminal rows into ring.term_pool, not env.terminal_obs)
-        stacks.append(fs.step(o, d, None).clone()); terms.append((d.clone(), ring.aux[ring.head - 1, 0, :, 3].clone()))
+        # (with the ring attached the kernel writes terminal rows into the slot's terminal section, not env.terminal_obs)
+        slot = ring.head - 1
+        tick = ring.tickets_at(slot, 0, torch.arange(E, device=env.device))
+        stacks.append(fs.step(o, d, None).clone()); terms.append((d.clone(), ring.terminal_at(slot, 0, tick.clamp(min=0).long()).clone()))
     g = torch.Generator(device=env.device).manual_seed(0)
     b = ring.sample_stacked(4096, k, generator=g)
     g = torch.Generator(device=env.device).manual_seed(0)          # replay the index draws
-    n_slots = ring.size - 1
+    n_slots = ring.sampleable() - 1
     j = torch.randint(0, n_slots, (4096,), generator=g, device=env.device)
     _ = torch.randint(0, 1, (4096,), generator=g, device=env.device)
     e = torch.randint(0, E, (4096,), generator=g, device=env.device)
@@ -270,7 +314,7 @@ def test_stacked_sampling_equals_frame_stack():
         assert torch.equal(b["obs"][i], stacks[s][ei]), (i, s, ei)
         d, tix = terms[s + 1]
         if d[ei]:      # SB3's stacked terminal_observation: [old frames shifted | terminal obs]
-            want = torch.cat([stacks[s][ei][D:], ring.term_pool[int(tix[ei])]])
+            want = torch.cat([stacks[s][ei][D:], tix[ei]])
             assert torch.equal(b["next_obs"][i], want); checked_term += 1
         else:
             assert torch.equal(b["next_obs"][i], stacks[s + 1][ei])

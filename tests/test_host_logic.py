@@ -61,19 +61,59 @@ def test_transition_ring_single_rank_cpu():
         ring.local_obs_slot().fill_(float(s))
         slot = ring.commit(torch.full((3,), s % 5), torch.full((3,), 10.0 * s), torch.tensor([0, 1, 0]))
         assert slot == s % 4
-    assert ring.size == 4 and ring.head == 2
+    assert ring.size == 3 and ring.head == 2            # the slot at the head is being recycled: capacity - 1 sampleable
     assert torch.equal(ring.obs[1, 0], torch.full((3, 5), 5.0))         # slot 1 now holds step 5
     b = ring.sample(64, generator=torch.Generator().manual_seed(0))
     assert b["obs"].shape == (64, 5) and b["next_obs"].shape == (64, 5)
     assert torch.all(b["next_obs"][:, 0] == b["obs"][:, 0] + 1)         # successor slot = next step
     assert torch.equal(b["reward"], b["next_obs"][:, 0] * 10.0)         # (a, r, done) are stored with the obs they produced
-    # done transitions without a pool entry are flagged invalid (next_obs would be the next episode's first obs)
+    # done transitions without a terminal row are flagged invalid (next_obs would be the next episode's first obs)
     assert torch.equal(b["valid"], ~b["done"])
-    ring.term_pool[5] = 77.0
-    ring.aux[:, 0, 1, 3] = 5.0                       # env 1 (always `done`) points at pool row 5
+    # with terminal observations committed the way the kernel does (ticket -> row of the slot's terminal section)
+    ring = TransitionRing(4, 3, 5, "cpu")
+    for s in range(6):
+        ring.local_obs_slot().fill_(float(s))
+        ring.commit(torch.full((3,), s % 5), torch.full((3,), 10.0 * s), torch.tensor([0, 1, 0]),
+                    terminal_obs=torch.full((3, 5), 77.0 + s))
     b = ring.sample(256, generator=torch.Generator().manual_seed(1))
     m = b["done"]
-    assert m.any() and b["valid"].all() and torch.all(b["next_obs"][m] == 77.0)
+    assert m.any() and b["valid"].all()
+    assert torch.all(b["next_obs"][m][:, 0] == 77.0 + b["obs"][m][:, 0] + 1)      # the terminal row written WITH the next slot
+    assert torch.all(b["next_obs"][~m][:, 0] == b["obs"][~m][:, 0] + 1)
+
+
+def test_transition_ring_detects_overwritten_terminal_rows():
+    """episode ends come in bursts.  A chunk whose terminal section is too small for its episode ends must
+    flag the overwritten rows (valid = False), never return another environment's observation."""
+    from uavenv_amd.replay import TransitionRing
+    E, D, L = 6, 3, 4
+    ring = TransitionRing(8, E, D, "cpu", chunk_len=L, terminal_rows=E)           # E rows per chunk of 4 slots
+    for s in range(8 + 3):
+        ring.local_obs_slot().copy_(torch.full((E, D), float(s)) + torch.arange(E).unsqueeze(1) * 0.01)
+        done = torch.ones(E) if s % 2 == 1 else torch.zeros(E)                    # every env ends on every odd step: 2 bursts per chunk
+        term = torch.full((E, D), 1000.0 + s) + torch.arange(E).unsqueeze(1) * 0.01
+        ring.commit(torch.zeros(E), torch.zeros(E), done, terminal_obs=term)
+    b = ring.sample(4000, generator=torch.Generator().manual_seed(0))
+    d, v = b["done"], b["valid"]
+    assert d.any() and (~v).any() and v[d].any() and v[~d].all()
+    # a valid terminal transition carries the terminal row of ITS OWN env and step
+    env_of = torch.round((b["obs"][:, 0] % 1) * 100)
+    step_of = torch.floor(b["obs"][:, 0])
+    want = 1000.0 + (step_of + 1) + env_of * 0.01
+    assert torch.allclose(b["next_obs"][d & v][:, 0], want[d & v], atol=1e-4)
+    # the window holds steps 4..10: the burst of step 5 was overwritten by the one of step 7 (same chunk) -> invalid; 7 is
+    # intact, and so is 9 (its chunk has not seen a second burst yet)
+    first_burst = d & ((step_of + 1) == 5)
+    assert first_burst.any() and (~v[first_burst]).all() and v[d & ~first_burst].all()
+    assert set((step_of[d] + 1).long().tolist()) == {5, 7, 9}
+    # with room for both bursts nothing is lost
+    ring = TransitionRing(8, E, D, "cpu", chunk_len=L, terminal_rows=2 * E)
+    for s in range(8 + 3):
+        ring.local_obs_slot().fill_(float(s))
+        done = torch.ones(E) if s % 2 == 1 else torch.zeros(E)
+        ring.commit(torch.zeros(E), torch.zeros(E), done, terminal_obs=torch.full((E, D), 1000.0 + s))
+    b = ring.sample(2000, generator=torch.Generator().manual_seed(0))
+    assert b["valid"].all() and torch.all(b["next_obs"][b["done"]][:, 0] == 1000.0 + b["obs"][b["done"]][:, 0] + 1)
 
 
 def _ring_worker(rank, world, port, q):
@@ -115,7 +155,28 @@ def _ring_worker(rank, world, port, q):
             stale = torch.arange(E * D, dtype=torch.float32).reshape(E, D) + 1000 * other + 100 * s
             ok &= not bool(torch.equal(ring.obs_at(slot, other, all_e), stale))
     b = ring.sample(32)
-    ok &= b["obs"].shape == (32, D) and ring.size == 8
+    ok &= b["obs"].shape == (32, D) and ring.size == 4 and ring.sampleable() == 4     # head at a chunk start: one whole chunk behind it
+    # EPISODE ENDS ACROSS RANKS: the terminal rows travel inside the chunk's collective, so a
+    # transition that ended an episode on the OTHER rank samples valid here, with that rank's terminal observation
+    ring = TransitionRing(8, E, D, "cpu", world_size=world, rank=rank, chunk_len=4)
+    for s in range(14):                                  # head ends mid-chunk: the incomplete chunk is not sampled
+        mine = torch.full((E, D), float(s)) + 1000 * rank + torch.arange(E).unsqueeze(1) * 0.01
+        ring.local_obs_slot().copy_(mine)
+        done = torch.zeros(E); done[(s + rank) % E] = 1.0                # one env per rank and step ends its episode
+        term = torch.full((E, D), 50000.0 + s) + 1000 * rank + torch.arange(E).unsqueeze(1) * 0.01
+        ring.commit(torch.full((E,), rank), torch.full((E,), float(s)), done, terminal_obs=term)
+    ok &= ring.sampleable() == 4
+    b = ring.sample(3000, generator=torch.Generator().manual_seed(5))
+    d = b["done"]
+    src_rank = torch.floor(b["obs"][:, 0] / 1000)
+    remote = src_rank == other
+    ok &= bool(remote.any()) and bool((d & remote).any()) and bool(b["valid"].all())
+    step_of = torch.floor(b["obs"][:, 0] % 1000)
+    env_of = torch.round((b["obs"][:, 0] % 1) * 100)
+    want_term = 50000.0 + (step_of + 1) + 1000 * src_rank + env_of * 0.01
+    ok &= bool(torch.allclose(b["next_obs"][d][:, 0], want_term[d], atol=1e-2))
+    ok &= bool(torch.allclose(b["next_obs"][~d][:, 0], (b["obs"][:, 0] + 1)[~d], atol=1e-2))
+    ok &= bool(torch.equal(env_of[d], ((step_of + 1 + src_rank) % E)[d]))       # the env that ended is the one the producer marked
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, ok))

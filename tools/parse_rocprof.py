@@ -44,9 +44,16 @@ def stats(d, out):
         short = name if len(name) < 90 else name[:87] + "..."
         lines.append(f"| `{short}` | {len(v)} | {sum(v)/1e6:.3f} | {sum(v)/len(v)/1e3:.3f} | {min(v)/1e3:.3f} | "
                      f"{max(v)/1e3:.3f} | {100*sum(v)/total:.1f} | {m[0]} | {m[1]} | {m[2]} | {m[3]} | {m[4]} | {m[5]} |")
+    lines.append(f"\ncommit: {build_commit()}")
     with open(out, "w") as f:
         f.write("\n".join(lines) + "\n")
     print("\n".join(lines))
+
+
+def build_commit():
+    """The commit tools/gpu.sh stamped into the tree before it was sent to the GPU box (None if it was not)."""
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".build_commit")
+    return open(p).read().strip() if os.path.exists(p) else None
 
 
 def pmc_avg(d, counter, kernel_substr):
@@ -63,7 +70,7 @@ def pmc(fetch_dir, write_dir, workload, out):
     k = "uav_step_kernel"
     fetch, nf = pmc_avg(fetch_dir, "FETCH_SIZE", k)
     write, nw = pmc_avg(write_dir, "WRITE_SIZE", k)
-    res = {"workload": workload, "kernel": k, "FETCH_SIZE_KiB_avg": fetch, "WRITE_SIZE_KiB_avg": write,
+    res = {"workload": workload, "kernel": k, "commit": build_commit(), "FETCH_SIZE_KiB_avg": fetch, "WRITE_SIZE_KiB_avg": write,
            "dispatches": [nf, nw],
            "hbm_bytes_per_launch": None if fetch is None or write is None else (2 * fetch + write) * 1024,
            "raw_bytes_per_launch": None if fetch is None or write is None else (fetch + write) * 1024,
