@@ -248,15 +248,15 @@ def test_replay_ring_with_terminal_pool():
     env.close()
 
 
-@pytest.mark.parametrize("L", [1, 8])
-def test_replay_ring_all_envs_end_on_the_same_step(L):
+@pytest.mark.parametrize("L,period", [(1, 7), (8, 3)])
+def test_replay_ring_all_envs_end_on_the_same_step(L, period):
     """Step-limit episodes end for EVERY environment on the same step (a pool sized for the average rate of
     episode ends hands out overwritten rows).  Terminal sections hold E rows per chunk, so no row is lost with one
     burst per chunk -- and when a chunk sees more episode ends than rows, the overwritten ones come back valid=False,
     never as another environment's observation."""
     torch, U, O = _mods()
     E = 1500                                            # more than the old default pool of 1024 rows
-    kw = dict(num_sensors=10, max_steps=7, grid_size=(60, 60), seed=4)
+    kw = dict(num_sensors=10, max_steps=period, grid_size=(60, 60), seed=4)
     env = U.BatchedUAVEnv(E, **kw)
     D = env.obs_dim
     ring = U.TransitionRing(32, E, D, env.device, chunk_len=L); ring.attach(env)
@@ -268,16 +268,16 @@ def test_replay_ring_all_envs_end_on_the_same_step(L):
         slot = ring.commit()
         per_step.append((slot, d.clone()))
     torch.cuda.synchronize()
-    assert all(bool(d.all()) == ((s % 7) == 0) for s, (slot, d) in enumerate(per_step[1:], 1))   # all end together, every 7th step
+    assert all(bool(d.all()) == ((s % period) == 0) for s, (slot, d) in enumerate(per_step[1:], 1))   # all end together
     b = ring.sample(20000, generator=torch.Generator(device=env.device).manual_seed(2))
     done = b["done"]
     assert done.any()
     if L == 1:                                          # one burst per chunk: nothing lost
         assert b["valid"].all()
-    else:                                               # a chunk of 8 slots can hold two bursts of E: the first is overwritten
+    else:                                               # a chunk of 8 slots sees two or three bursts of E ends: only the last survives
         assert (~b["valid"]).any() and b["valid"][done].any()
     # every valid terminal transition carries ITS OWN environment's terminal observation: header = position / battery of a
-    # UAV that has flown 7 steps, never the (0, 0, 1) header of a freshly reset one
+    # UAV that has flown `period` steps, never the (0, 0, 1) header of a freshly reset one
     nxt = b["next_obs"][done & b["valid"]]
     assert (nxt[:, 2] < 1.0).all()
     env.close()

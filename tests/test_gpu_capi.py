@@ -166,7 +166,7 @@ def test_action_words_never_outlive_the_seed_or_the_state():
 
 def test_ring_chunk_graphs_equal_the_eager_loop():
     """TransitionRing.capture_chunks: one HIP graph per ring chunk (the bench's launch path) produces the same ring
-    contents, terminal pool and environment state as stepping from Python."""
+    contents, terminal rows and environment state as stepping from Python."""
     import torch
     import uavenv_amd as U
     from uavenv_amd.replay import TransitionRing
@@ -174,7 +174,7 @@ def test_ring_chunk_graphs_equal_the_eager_loop():
     envs, rings = [], []
     for chunk in (1, 4):
         e = U.BatchedUAVEnv(300, **kw)
-        r = TransitionRing(8, 300, e.obs_dim, e.device, terminal_rows=4096, chunk_len=chunk)
+        r = TransitionRing(8, 300, e.obs_dim, e.device, chunk_len=chunk)
         r.attach(e); e.reset()
         envs.append(e); rings.append(r)
     (ea, eb), (ra, rb) = envs, rings
@@ -183,22 +183,25 @@ def test_ring_chunk_graphs_equal_the_eager_loop():
         eb.step_random(obs_out=rb.local_obs_slot()); rb.commit()
     graphs = rb.capture_chunks(lambda slot: eb.step_random(obs_out=slot))
     all_e = torch.arange(300, device=ea.device)
+    n_term = 0
     for rev in range(3):
         for _ in range(8):
             ea.step_random(obs_out=ra.local_obs_slot()); ra.commit()
         rb.replay_chunk(graphs); rb.replay_chunk(graphs)
         torch.cuda.synchronize()
-        assert ra.size == rb.size == 8 and ra.head == rb.head
-        # terminal-pool rows are handed out by an atomic counter (order of arrival): compare what the rows hold
-        assert int(ra.term_counter.item()) == int(rb.term_counter.item()) > 0
+        # a ring recycles the chunk at its head as a whole: 8 - 1 sampleable slots with chunks of 1, 8 - 4 with chunks of 4
+        assert ra.head == rb.head == 0 and ra.size == 7 and rb.size == 4
+        # terminal rows are handed out by an atomic counter (order of arrival): compare what the rows hold
         for slot in range(8):
             aa, ab = ra.aux_at(slot, 0, all_e), rb.aux_at(slot, 0, all_e)
             assert torch.equal(ra.obs_at(slot, 0, all_e), rb.obs_at(slot, 0, all_e)) and torch.equal(aa[:, :3], ab[:, :3])
-            rows_a, rows_b = aa[:, 3].long(), ab[:, 3].long()
-            assert torch.equal(rows_a >= 0, rows_b >= 0)
-            m = rows_a >= 0
+            ta, tb = ra.tickets_at(slot, 0, all_e).long(), rb.tickets_at(slot, 0, all_e).long()
+            assert torch.equal(ta >= 0, tb >= 0) and torch.equal(ta >= 0, aa[:, 2] > 0.5)
+            m = ta >= 0
             if bool(m.any()):
-                assert torch.equal(ra.term_pool[rows_a[m]], rb.term_pool[rows_b[m]])
+                assert torch.equal(ra.terminal_at(slot, 0, ta[m]), rb.terminal_at(slot, 0, tb[m]))
+                n_term += int(m.sum())
+    assert n_term > 300
     sa, sb = ea.state_dict(), eb.state_dict()
     assert all(torch.equal(sa[k], sb[k]) for k in sa)
     batch = rb.sample(256)

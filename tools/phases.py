@@ -30,7 +30,8 @@ for E in [int(x) for x in os.environ.get("ES", "256,4096").split(",")]:
     env = U.BatchedUAVEnv(E, num_sensors=50, seed=0)
     L = N.lib()
     L.uavenv_debug_set_stamps.argtypes = [C.c_void_p, C.c_void_p]
-    stamps = torch.zeros((1 << 20) + E * 16 + 64, dtype=torch.int64, device=env.device)
+    assert E * 8 <= (1 << 20)
+    stamps = torch.zeros((1 << 20) + (E + 64) * 16, dtype=torch.int64, device=env.device)   # padded environments stamp too
     env.reset()
     for _ in range(200):
         env.step_random()
@@ -43,8 +44,9 @@ for E in [int(x) for x in os.environ.get("ES", "256,4096").split(",")]:
     ph = raw[(1 << 20): (1 << 20) + E * 16].reshape(E, 16)    # per environment
     # map env -> wave slot start time: the wave that stepped env e recorded phases for env e; its t0 is in w[slot] where
     # slot is unknown under balancing, so match through the end stamp: use per-block sets instead (same block)
-    t0_blk = w[:, 0].reshape(-1, 16).min(axis=1) if E >= 16 else w[:, 0].min(keepdims=True)
-    t0 = np.repeat(t0_blk, 16)[:E]
+    wpb = 16 if E >= 4096 else 4               # waves per workgroup (launch_step: 16-wave workgroups once every CU gets 16)
+    t0_blk = w[:, 0].reshape(-1, wpb).min(axis=1)
+    t0 = np.repeat(t0_blk, wpb)[:E]
     act = np.zeros(E, dtype=np.int64)
     # the action per env: recover from the aux-free path -> use env.last actions via records? use the wave record instead
     rel = ph[:, :8] - t0[:, None]

@@ -29,7 +29,8 @@ env = U.BatchedUAVEnv(E, num_sensors=n, seed=0)
 L = N.lib()
 L.uavenv_debug_set_stamps.argtypes = [C.c_void_p, C.c_void_p]
 nw = (E * env.lane_stride + 63) // 64
-stamps = torch.zeros(nw * 8 + 64, dtype=torch.int64, device=env.device)
+stamps = torch.zeros((1 << 20) + (E + 64) * 16, dtype=torch.int64, device=env.device)   # per-wave records, then the phase stamps at word 1 << 20 (UAV_PHASE)
+assert nw * 8 <= (1 << 20)
 env.reset()
 for _ in range(300):
     env.step_random()
