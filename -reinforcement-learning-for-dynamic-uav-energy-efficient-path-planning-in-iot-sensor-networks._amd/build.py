@@ -11,7 +11,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libuavenv_hip.so")
 SOURCES = ["uavenv_kernels.hip", "uavenv_capi.hip", "uavenv_attention.hip"]
-HEADERS = ["uavenv_internal.h", "uavenv_noise.h", os.path.join("..", "..", "include", "uavenv.h")]
+HEADERS = ["uavenv_internal.h", "uavenv_noise.h", "uavenv_derive.h", "uavenv_default_consts.inc", "gen_default_consts.cpp",
+           os.path.join("..", "..", "include", "uavenv.h")]
+GENERATED = os.path.join(CSRC, "uavenv_default_consts.inc")
 # -ffp-contract=off: the float64 state has to follow the reference's (numpy, unfused) operation order.
 # kernarg preload: the leading scalar kernel arguments arrive in SGPRs with the wave launch (see uav_step_kernel).
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall", "-Wno-bitwise-instead-of-logical",
@@ -33,9 +35,27 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def generate_default_consts(verbose=False):
+    """csrc/uavenv_default_consts.inc: the default configuration's derived constants as exact hex-float literals, printed by
+    a host program built from the SAME uavenv_derive.h the C ABI uses (the kernels' literal specialisation includes it).
+    The file is committed (the GPU box's dev tools compile the kernels too); it is rewritten only when its content changes."""
+    gen = os.path.join(CSRC, "_gen_default_consts")
+    subprocess.check_call([hipcc(), "-O1", "-std=c++17", "-o", gen, os.path.join(CSRC, "gen_default_consts.cpp")],
+                          stderr=None if verbose else subprocess.DEVNULL)
+    try:
+        text = subprocess.check_output([gen]).decode()
+    finally:
+        os.remove(gen)
+    if not os.path.exists(GENERATED) or open(GENERATED).read() != text:
+        with open(GENERATED, "w") as f:
+            f.write(text)
+    return text
+
+
 def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
+    generate_default_consts(verbose)
     cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "uavenv_internal.h"
+#include "uavenv_derive.h"
 
 using namespace uavenv;
 
@@ -34,6 +35,11 @@ struct UavEnv {
     uint32_t* hints = nullptr;      // [2][padded_envs] scheduling hints of the random-policy step (StepArgs::balance)
     int hint_parity = 0;
     bool balance = true;            // UAVENV_NO_BALANCE=1 in the environment keeps the home mapping (A/B timing)
+    bool default_consts = false;    // constants bit-identical to the default configuration's: the literal specialisation may run
+                                    // (UAVENV_NO_LITERALS=1 in the environment at create time keeps the generic kernels, for A/B runs)
+    bool allow_literals = true;
+    bool write_through = false;     // sc1 stores for observations / sensor state (StepArgs::write_through): batches of >= 4096 wavefronts;
+                                    // UAVENV_WRITE_THROUGH=0 / 1 in the environment at create time forces it off / on (A/B runs)
     std::string err;
 };
 
@@ -54,98 +60,11 @@ extern "C" int uavenv_abi_version(void) { return UAVENV_ABI_VERSION; }
 
 extern "C" int uavenv_default_config(UavEnvConfig* c) {
     if (!c) return UAVENV_E_INVALID;
-    std::memset(c, 0, sizeof(*c));
-    c->struct_size = (uint32_t)sizeof(*c);
-    c->grid_w = 500; c->grid_h = 500;                 // dqn.py EVAL_GRID / BASELINE configs
-    c->num_sensors = 20;                              // uav_env.py:270
-    c->max_steps = 2100;                              // dqn.py:1069
-    c->include_sensor_positions = 0;                  // uav_env.py:286
-    c->pad_sensors = 0;
-    c->flags = 0;
-    c->max_start_tries = 200;                         // dqn.py NAV_CONFIG
-    c->use_ema_adr = 1;                               // iot_sensors.py:54
-    c->num_grid_choices = 0;
-    c->seed = 0;
-    c->data_generation_rate = 22.0 / 10;              // uav_env.py:271
-    c->max_buffer_size = 1000.0;                      // :272
-    c->rssi_threshold = -85.0;                        // :275
-    c->duty_cycle = 10.0;                             // :276
-    c->start_x = 0.0; c->start_y = 0.0;               // :322-323
-    c->max_battery = 274.0;                           // :278
-    c->collection_duration = 1.0;                     // :279
-    c->tx_power_dbm = 14.0;                           // iot_sensors.py:45
-    c->noise_floor_dbm = -105.0;                      // :49
-    c->uav_altitude = 100.0;                          // :50
-    c->sensor_height = 0.5;                           // :170
-    c->wavelength = 0.345;                            // :174
-    c->freq_mhz = 868.0; c->fspl_offset_db = 28.0;    // :179
-    c->adr_lambda = 0.1;                              // :53
-    c->shadowing_std_db = 4.0;                        // :55
-    c->capture_threshold_db = 6.0;                    // uav_env.py:567
-    c->sf_thresholds[0] = -60.0; c->sf_thresholds[1] = -70.0;   // iot_sensors.py:32-37
-    c->sf_thresholds[2] = -78.0; c->sf_thresholds[3] = -85.0;
-    c->fill_lo = 0.20; c->fill_hi = 0.60;             // uav_env.py:410
-    c->power_move = 500.0; c->power_hover = 700.0;    // uav.py:93-94
-    c->alive_fraction = 0.02;                         // uav.py:224
-    c->reward_per_byte = 100.0; c->reward_new_sensor = 5000.0; c->reward_completion = 100.0;   // reward_function.py:9-11
-    c->reward_urgency_reduction = 20.0;               // uav_env.py:283
-    c->reward_movement = 10.0;                        // :285
-    c->penalty_revisit = -2.0; c->penalty_boundary = -50.0; c->penalty_collision = -10.0;      // reward_function.py:15-17
-    c->penalty_battery = -0.5;                        // uav_env.py:284
-    c->penalty_hover = -5.0; c->penalty_step = -0.5;  // reward_function.py:19-20
-    c->penalty_data_loss = -1.0;                      // uav_env.py:282
-    c->penalty_starvation = -1000.0; c->penalty_unvisited = -5000.0; c->penalty_starved = -1000.0;
-    c->starvation_cr_threshold = 0.20;                // reward_function.py:22-25
-    c->min_start_dist = 50.0; c->prox_eta = 2.0;      // dqn.py NAV_CONFIG
-    c->jain_weight = 0.5;                             // dqn.py:442
+    fill_default_config(c);
     return UAVENV_OK;
 }
 
-static int obs_dim_of(const UavEnvConfig* c) {
-    int fps = c->include_sensor_positions ? 5 : 3;
-    int slots = c->pad_sensors > c->num_sensors ? c->pad_sensors : c->num_sensors;
-    return 3 + fps * slots;
-}
 extern "C" int uavenv_obs_dim(const UavEnvConfig* c) { return c ? obs_dim_of(c) : UAVENV_E_INVALID; }
-
-// Derived constants: each with the reference's own expression.
-static void derive_consts(const UavEnvConfig& c, Consts& k) {
-    std::memset(&k, 0, sizeof(k));
-    k.seed = c.seed;
-    k.rate = c.data_generation_rate; k.bmax = c.max_buffer_size; k.thr = c.rssi_threshold;
-    k.inv_bmax = 1.0 / c.max_buffer_size; k.inv_maxb = 1.0 / c.max_battery;
-    k.inv_rate = c.data_generation_rate > 0 ? 1.0 / c.data_generation_rate : 0.0;
-    k.p_cycle = c.duty_cycle / 100.0;                                    // iot_sensors.py:105-107
-    k.maxb = c.max_battery; k.coll_dur = c.collection_duration;
-    k.sigma = c.shadowing_std_db; k.lambda = c.adr_lambda; k.one_minus_lambda = 1 - c.adr_lambda;
-    k.tx_power = c.tx_power_dbm; k.noise_floor = c.noise_floor_dbm; k.cap_thr = c.capture_threshold_db;
-    k.d_break = (4 * M_PI * c.sensor_height * c.uav_altitude) / c.wavelength;   // iot_sensors.py:174
-    k.c_fs = 20 * std::log10(c.freq_mhz); k.fspl_off = c.fspl_offset_db;        // :179
-    k.c_ht = 20 * std::log10(c.sensor_height); k.c_hr = 20 * std::log10(c.uav_altitude);   // :183
-    for (int i = 0; i < 4; i++) k.sf_thr[i] = c.sf_thresholds[i];
-    k.fill_lo = c.fill_lo; k.fill_span = c.fill_hi - c.fill_lo;
-    double time_step = 1.0;
-    k.e_move = (c.power_move * time_step) / 3600;                        // uav.py:176
-    k.e_coll = ((c.power_move * 0.5) * time_step) / 3600;                // uav.py:125,180
-    k.e_hover = (c.power_hover * c.collection_duration) / 3600;          // uav.py:204
-    k.used_hover = (c.power_hover / (60 * 60)) * c.collection_duration;  // uav.py:260-263, uav_env.py:530
-    k.alive_level = c.alive_fraction * c.max_battery;                    // uav.py:224
-    k.r_byte = c.reward_per_byte; k.r_new = c.reward_new_sensor; k.r_done = c.reward_completion;
-    k.r_urg = c.reward_urgency_reduction; k.r_move = c.reward_movement; k.p_revisit = c.penalty_revisit;
-    k.p_boundary = c.penalty_boundary; k.p_collision = c.penalty_collision; k.p_battery = c.penalty_battery;
-    k.p_hover = c.penalty_hover; k.p_step = c.penalty_step; k.p_loss = c.penalty_data_loss;
-    k.p_starvation = c.penalty_starvation; k.p_unvisited = c.penalty_unvisited; k.p_starved = c.penalty_starved;
-    k.cr_thr = c.starvation_cr_threshold;
-    k.min_start_dist = c.min_start_dist; k.prox_eta = c.prox_eta; k.jain_weight = c.jain_weight;
-    k.alt2 = (float)(c.uav_altitude * c.uav_altitude);                   // iot_sensors.py:164
-    k.max_steps = c.max_steps; k.fps = c.include_sensor_positions ? 5 : 3; k.obs_dim = obs_dim_of(&c);
-    k.obs_slots = (k.obs_dim - 3) / k.fps;
-    k.max_tries = c.max_start_tries; k.use_ema = c.use_ema_adr; k.n_grid_choices = c.num_grid_choices;
-    k.flags = c.flags;
-    for (int i = 0; i < 8; i++) { k.gw[i] = c.grid_choices_w[i]; k.gh[i] = c.grid_choices_h[i]; }
-    k.inv_small[0] = 0.0;
-    for (int i = 1; i <= 64; i++) k.inv_small[i] = 1.0 / (double)i;
-}
 
 static size_t field_elem_bytes(int field) {
     switch (field) {
@@ -193,6 +112,13 @@ extern "C" int uavenv_create(const UavEnvConfig* cfg, int32_t num_envs, uint32_t
     const int per_block = kBlockThreads / e->G;
     e->padded_envs = ((num_envs + per_block - 1) / per_block) * per_block;
     derive_consts(e->cfg, e->consts);
+    { const char* nl = getenv("UAVENV_NO_LITERALS"); e->allow_literals = !(nl && nl[0] == '1'); }
+#ifdef UAV_FORCE_NOLIT      // A/B timing builds (tools/exp.sh)
+    e->allow_literals = false;
+#endif
+    e->default_consts = e->allow_literals && consts_are_default(e->consts);
+    e->write_through = step_uses_big_workgroups(e->G, e->padded_envs);
+    { const char* wt = getenv("UAVENV_WRITE_THROUGH"); if (wt && (wt[0] == '0' || wt[0] == '1')) e->write_through = wt[0] == '1'; }
     auto bail = [&](int code, const std::string& m) { uavenv_destroy(e); return fail(nullptr, code, m); };
     hipError_t st = hipSetDevice(device);
     if (st != hipSuccess) return bail(UAVENV_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(st));
@@ -325,14 +251,14 @@ static int step_common(UavEnv* e, int32_t policy, const int32_t* actions, int32_
     if (policy < UAVENV_POLICY_ACTIONS || policy > UAVENV_POLICY_MAX_THROUGHPUT_V2) return fail(e, UAVENV_E_INVALID, "unknown policy");
     if (policy == UAVENV_POLICY_ACTIONS && !actions) return fail(e, UAVENV_E_INVALID, "actions_dev is NULL");
     StepArgs a{actions, actions_out, obs, rew, rew32, done, term, e->num_envs,
-               e->term_pool, e->term_counter, e->term_index, e->term_rows, policy, e->aux_out, nullptr, nullptr, 0};
+               e->term_pool, e->term_counter, e->term_index, e->term_rows, policy, e->aux_out, nullptr, nullptr, 0, e->write_through ? 1 : 0};
     a.hint_in = e->hints + (size_t)e->hint_parity * (size_t)e->padded_envs;          // always a readable buffer
     a.balance = e->balance ? 1 : 0;
     if (policy == UAVENV_POLICY_RANDOM) {                         // this launch leaves the next launch's action words
         a.hint_out = e->hints + (size_t)(e->hint_parity ^ 1) * (size_t)e->padded_envs;
         e->hint_parity ^= 1;
     } else if (policy != UAVENV_POLICY_ACTIONS) a.balance = 0;   // no cheap way to know the actions up front
-    HIP_TRY(e, launch_step(e->G, e->padded_envs, e->consts, e->dev_consts, e->ptrs, a, (hipStream_t)stream));
+    HIP_TRY(e, launch_step(e->G, e->padded_envs, e->consts, e->dev_consts, e->ptrs, a, e->default_consts, (hipStream_t)stream));
     return UAVENV_OK;
 }
 
@@ -361,8 +287,8 @@ extern "C" int uavenv_rollout(UavEnv* e, int32_t num_steps, int32_t policy, cons
     if (e->aux_out != nullptr && num_steps > e->aux_capacity)
         return fail(e, UAVENV_E_INVALID, "rollout of more steps than the attached aux output holds ([K][E][4] blocks): detach it or attach a larger one");
     StepArgs a{actions_dev, actions_out, obs, rew, rew32, done, term, e->num_envs,
-               e->term_pool, e->term_counter, nullptr, e->term_rows, policy, e->aux_out, nullptr, nullptr, 0};   // aux [K][E][4] carries the pool rows
-    HIP_TRY(e, launch_rollout(e->G, e->padded_envs, e->consts, e->dev_consts, e->ptrs, a, num_steps, (hipStream_t)stream));
+               e->term_pool, e->term_counter, nullptr, e->term_rows, policy, e->aux_out, nullptr, nullptr, 0, e->write_through ? 1 : 0};   // aux [K][E][4] carries the tickets
+    HIP_TRY(e, launch_rollout(e->G, e->padded_envs, e->consts, e->dev_consts, e->ptrs, a, num_steps, e->default_consts, (hipStream_t)stream));
     return UAVENV_OK;
 }
 

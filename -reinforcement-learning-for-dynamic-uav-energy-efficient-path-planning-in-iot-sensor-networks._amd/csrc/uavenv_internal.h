@@ -104,6 +104,8 @@ struct StepArgs {
     const uint32_t* hint_in;    // never null (one word per padded environment)
     uint32_t* hint_out;         // null unless the random policy writes next-step hints
     int32_t balance;
+    int32_t write_through;      // observation and sensor-state stores as `sc1` write-through stores (batches that fill the chip: the
+                                // kernel boundary then has no dirty L2 lines to write back); any value gives the same results
 };
 
 struct ResetArgs {
@@ -117,9 +119,12 @@ hipError_t launch_init(int G, int padded_envs, const Consts& c, const Consts* de
                        int32_t grid_w, int32_t grid_h, int32_t n, float start_x, float start_y, hipStream_t s);
 hipError_t launch_reset(int G, int padded_envs, const Consts& c, const Consts* dev_consts, const Ptrs& p, const ResetArgs& a, hipStream_t s);
 bool step_uses_big_workgroups(int G, int padded_envs);   // 16-wave workgroups + SIMD load balancing, else 4-wave
-hipError_t launch_step(int G, int padded_envs, const Consts& c, const Consts* dev_consts, const Ptrs& p, const StepArgs& a, hipStream_t s);
+// default_consts: the handle's constants equal uavenv_default_config()'s bit for bit (consts_are_default) -> the variant
+// that reads them as instruction literals may run (it is also restricted to the lean configuration)
+hipError_t launch_step(int G, int padded_envs, const Consts& c, const Consts* dev_consts, const Ptrs& p, const StepArgs& a,
+                       bool default_consts, hipStream_t s);
 hipError_t launch_rollout(int G, int padded_envs, const Consts& c, const Consts* dev_consts, const Ptrs& p, const StepArgs& a,
-                          int32_t num_steps, hipStream_t s);
+                          int32_t num_steps, bool default_consts, hipStream_t s);
 hipError_t launch_frame_stack(float* stacked, const float* obs, const uint8_t* done, const float* terminal_obs,
                               float* terminal_stacked, int32_t num_envs, int32_t k, int32_t D, hipStream_t s);
 hipError_t launch_dump_noise(int G, int padded_envs, const Consts& c, const Consts* dev_consts, const Ptrs& p, float* step_tape,

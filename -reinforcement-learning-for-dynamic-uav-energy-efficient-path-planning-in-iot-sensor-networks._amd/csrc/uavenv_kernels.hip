@@ -27,6 +27,15 @@
 
 namespace uavenv {
 
+// timing-only ablation builds (tools/exp.sh "exitK=-DUAV_ABL_EXIT=K"): the step ends after phase K; `val` keeps what the phases
+// so far computed alive.  The kernel time of successive K's shows what each phase adds to a LAUNCH (overlap included).
+#ifdef UAV_ABL_EXIT
+#define UAV_EXIT_AT(k, val) do { if (UAV_ABL_EXIT == (k)) { if (gl == 0 && a.hint_out != nullptr) a.hint_out[env] = (uint32_t)(val); \
+                                                            live = false; next_word = 0u; action_out = 0; return; } } while (0)
+#else
+#define UAV_EXIT_AT(k, val) do {} while (0)
+#endif
+
 #ifdef UAVENV_STAMPS
 // diagnostic build: phase timestamps of the step, 16 words per environment, stored behind the per-wave records
 // (p.stamps + kPhaseBase); tools/phases.py reads them.
@@ -49,6 +58,32 @@ typedef const __attribute__((address_space(4))) Consts& CRef;
 #define UAV_TAPE(ptr) (kLean ? (const float*)nullptr : (ptr))
 #define UAV_POLICY(a) (kLean ? ((a).policy & 1) : (a).policy)
 #define UAV_CONSTS(ptr) CRef c = *(const __attribute__((address_space(4))) Consts*)(ptr)
+
+// "Default constants" specialisation (template parameter kDefC of the step / rollout kernels).  Every scalar load of a
+// constant is a round trip to the scalar cache on the critical path of a wave (56 cycles on a hit, 165 on the first touch
+// of a 64-byte line after a launch, tools/smem_latency.hip) and a step reads ~45 of them: for the reference's own
+// configuration (uavenv_default_config: BASE_ENV_CONFIG, dqn.py:1068-1075) the floating-point constants are therefore
+// also available as instruction literals, generated bit for bit from the same derive_consts() by gen_default_consts.cpp.
+// launch_step / launch_rollout pick this variant only when the handle's constants block is bit-identical
+// (consts_are_default); everything that is not a floating-point constant (seed, step limit, observation shape, flags, the
+// reciprocal table) still comes from the block `m`.
+typedef const __attribute__((address_space(4))) int32_t& CI32;
+struct DefaultConsts {
+    CRef m;
+    const __attribute__((address_space(4))) uint64_t& seed;
+    CI32 max_steps, fps, obs_dim, obs_slots, use_ema, max_tries, n_grid_choices;
+    const __attribute__((address_space(4))) uint32_t& flags;
+    const __attribute__((address_space(4))) int32_t (&gw)[8];
+    const __attribute__((address_space(4))) int32_t (&gh)[8];
+    const __attribute__((address_space(4))) double (&inv_small)[65];
+#include "uavenv_default_consts.inc"
+    __device__ __forceinline__ explicit DefaultConsts(CRef k)
+        : m(k), seed(k.seed), max_steps(k.max_steps), fps(k.fps), obs_dim(k.obs_dim), obs_slots(k.obs_slots), use_ema(k.use_ema),
+          max_tries(k.max_tries), n_grid_choices(k.n_grid_choices), flags(k.flags), gw(k.gw), gh(k.gh), inv_small(k.inv_small) {}
+};
+template <bool kDefC> struct ConstsSel;
+template <> struct ConstsSel<false> { static __device__ __forceinline__ CRef make(CRef k) { return k; } };
+template <> struct ConstsSel<true> { static __device__ __forceinline__ DefaultConsts make(CRef k) { return DefaultConsts(k); } };
 
 // ---------------------------------------------------------------------------------------------
 // lane-group primitives (G lanes of a wave64)
@@ -237,7 +272,7 @@ __device__ __forceinline__ float log10_f32(float d) {
     return (float)r;
 }
 
-__device__ __forceinline__ double rssi_deterministic(CRef c, float ux, float uy, float sx, float sy) {
+template <typename CT> __device__ __forceinline__ double rssi_deterministic(const CT& c, float ux, float uy, float sx, float sy) {
     float dx = (ux - sx) * 10.0f;
     float dy = (uy - sy) * 10.0f;
     float ground = sqrt_rn(dx * dx + dy * dy);
@@ -255,7 +290,7 @@ __device__ __forceinline__ double rssi_deterministic(CRef c, float ux, float uy,
 }
 
 // iot_sensors.py:223-259 update_spreading_factor (EMA-ADR), state in (avg, flags)
-__device__ __forceinline__ void adr_update(CRef c, double cur, double& avg, uint32_t& flags) {
+template <typename CT> __device__ __forceinline__ void adr_update(const CT& c, double cur, double& avg, uint32_t& flags) {
     const bool ema = ((flags & kAvgValid) != 0u) & (c.use_ema != 0);
     const double blended = (c.lambda * cur) + (c.one_minus_lambda * avg);
     const double nv = ema ? blended : cur;
@@ -279,7 +314,7 @@ __device__ __forceinline__ double div_const(double x, double y, double inv) {
 }
 
 // uav_env.py:376-384 _calculate_urgency
-__device__ __forceinline__ double calc_urgency(CRef c, double b, double gen, double lost) {
+template <typename CT> __device__ __forceinline__ double calc_urgency(const CT& c, double b, double gen, double lost) {
     double util = div_const(b, c.bmax, c.inv_bmax);
     double loss_rate = gen > 0 ? lost / gen : 0.0;
     double u = util * (1.0 + loss_rate * 10.0);
@@ -327,6 +362,23 @@ template <int G, typename RP> __device__ __forceinline__ Env load_env(RP rp) {
     return e;
 }
 
+// Write-through stores.  A plain store leaves its line dirty in the XCD's L2 and the kernel boundary writes all dirty lines
+// back (the XCDs' L2s are not coherent with each other): ~10 MB per launch at 4096 environments, 1.4 us of a 9 us launch
+// (timing-only builds without the state / observation stores, tools/exp.sh).  `sc1` stores leave L2 while the launch is
+// still computing (MI355X_MICROARCH.md "stores of each flavour"); measured 9.05 -> 8.52 us per launch at 4096 environments
+// for observations + sensor state, `nt` 8.79.  They also drop the line from L2, so the next launch's loads come from the
+// Infinity Cache: +0.18 us at 256 environments, where there is little to write back -- so `wt` is a launch parameter
+// (StepArgs::write_through, set for batches that fill the chip).
+template <typename T> __device__ __forceinline__ void store_wt(T* q, T v, bool wt) {
+    if (wt) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // global_store ... sc1
+    else *q = v;
+}
+typedef float __attribute__((ext_vector_type(3))) f32x3;
+__device__ __forceinline__ void store3_wt(float* q, float a, float b, float c, bool wt) {
+    if (wt) { f32x3 v = {a, b, c}; asm volatile("global_store_dwordx3 %0, %1, off sc1" :: "v"(q), "v"(v) : "memory"); }
+    else { struct __attribute__((packed, aligned(4))) P3 { float a, b, c; }; P3 w{a, b, c}; *reinterpret_cast<P3*>(q) = w; }
+}
+
 // per-lane sensor registers
 struct Sensor {
     double b, gen, tx, lost, avg;
@@ -357,15 +409,18 @@ template <int G, typename P> __device__ __forceinline__ void load_sensor(const P
 // their state never changes), `tx` only if some lane of the wave collected or reset (compared with the loaded value),
 // `lost` only if some buffer overflowed or reset.  Cuts the write traffic by about a third.
 template <int G, typename P> __device__ __forceinline__ void store_sensor(const P& p, uint32_t idx, const Sensor& s, bool with_pos,
-                                                                          bool live, double tx0, double lost0) {
+                                                                          bool live, double tx0, double lost0, bool wt) {
+#ifdef UAV_ABL_NOSTATE        // timing-only ablation build
+    if (s.b != -1.0) return;
+#endif
     if (with_pos && live) { sensor_at<float>(p, kOffPosX, idx) = s.sx; sensor_at<float>(p, kOffPosY, idx) = s.sy; }
     if (live) {
-        sensor_at<double>(p, kOffBuffer, idx) = s.b; sensor_at<double>(p, kOffGen, idx) = s.gen;
-        sensor_at<double>(p, kOffAvg, idx) = s.avg;
-        sensor_at<uint32_t>(p, kOffFlags, idx) = s.flags;
+        store_wt(&sensor_at<double>(p, kOffBuffer, idx), s.b, wt); store_wt(&sensor_at<double>(p, kOffGen, idx), s.gen, wt);
+        store_wt(&sensor_at<double>(p, kOffAvg, idx), s.avg, wt);
+        store_wt(&sensor_at<uint32_t>(p, kOffFlags, idx), s.flags, wt);
     }
-    if (__any(live & (s.tx != tx0)) && live) sensor_at<double>(p, kOffTx, idx) = s.tx;
-    if (__any(live & (s.lost != lost0)) && live) sensor_at<double>(p, kOffLost, idx) = s.lost;
+    if (__any(live & (s.tx != tx0)) && live) store_wt(&sensor_at<double>(p, kOffTx, idx), s.tx, wt);
+    if (__any(live & (s.lost != lost0)) && live) store_wt(&sensor_at<double>(p, kOffLost, idx), s.lost, wt);
 }
 // unconditional form (initialisation, reset kernel)
 template <int G, typename P> __device__ __forceinline__ void store_sensor(const P& p, uint32_t idx, const Sensor& s, bool with_pos) {
@@ -409,10 +464,10 @@ template <int G> __device__ __forceinline__ double jains_index(const Sensor& s, 
 // wave may hold groups that do not rebuild); `dst` may be nullptr (row computed for its side effects only).
 struct __attribute__((packed, aligned(4))) ObsF3 { float a, b, c; };
 struct __attribute__((packed, aligned(4))) ObsF2 { float a, b; };
-template <int G, bool kLean>
-__device__ __forceinline__ void observe(CRef c, Sensor& s, int n, int gw, int gh, double inv_w, double inv_h,
+template <int G, bool kLean, typename CT>
+__device__ __forceinline__ void observe(const CT& c, Sensor& s, int n, int gw, int gh, double inv_w, double inv_h,
                                         float uxf, float uyf, double battery, bool act, bool enable,
-                                        double det, float zD, float zE, float* dst) {
+                                        double det, float zD, float zE, float* dst, bool wt = false) {
     const int gl = group_lane<G>();
     double W = (double)gw, H = (double)gh;
     double ux = (double)uxf, uy = (double)uyf;
@@ -429,13 +484,13 @@ __device__ __forceinline__ void observe(CRef c, Sensor& s, int n, int gw, int gh
             f4 = (float)div_const((double)s.sy - uy, H, inv_h);
         }
     }
+#ifdef UAV_ABL_NOOBS          // timing-only ablation build
+    if (f0 != -7.0f) dst = nullptr;
+#endif
     if (enable && dst != nullptr) {
         if (gl == 0) {
-            ObsF3 h;
-            h.a = (float)div_const(ux, W, inv_w);
-            h.b = (float)div_const(uy, H, inv_h);
-            h.c = (float)div_const(battery, c.maxb, c.inv_maxb);
-            *reinterpret_cast<ObsF3*>(dst) = h;
+            store3_wt(dst, (float)div_const(ux, W, inv_w), (float)div_const(uy, H, inv_h),
+                      (float)div_const(battery, c.maxb, c.inv_maxb), wt);
         }
         // slot gl holds this lane's sensor (zeros beyond n: the padded tail of dqn.py:286-298); groups narrower
         // than the padded row (num_sensors <= 32 padded to 50) zero the remaining slots in further passes
@@ -444,8 +499,7 @@ __device__ __forceinline__ void observe(CRef c, Sensor& s, int n, int gw, int gh
         for (int k = gl; k < slots; k += G) {
             const bool own = k == gl;
             float* q = dst + 3 + fps * k;
-            ObsF3 v; v.a = own ? f0 : 0.f; v.b = own ? f1 : 0.f; v.c = own ? f2 : 0.f;
-            *reinterpret_cast<ObsF3*>(q) = v;
+            store3_wt(q, own ? f0 : 0.f, own ? f1 : 0.f, own ? f2 : 0.f, wt);
             if (fps == 5) { ObsF2 w; w.a = own ? f3 : 0.f; w.b = own ? f4 : 0.f; *reinterpret_cast<ObsF2*>(q + 3) = w; }
         }
     }
@@ -457,8 +511,8 @@ __device__ __forceinline__ void observe(CRef c, Sensor& s, int n, int gw, int gh
 struct StepNoise { float zA, zB, u, zC, zD, zE; uint32_t c2, c3; bool zc_ready; uint32_t w3; bool have_w3; };
 
 // zP: the shadowing sample of the is_in_range() call a heuristic policy makes before the step (Philox call 5)
-template <int G, bool kLean, typename P>
-__device__ __forceinline__ float draw_policy_noise(CRef c, const P& p, uint32_t env_index, uint32_t episode, size_t env,
+template <int G, bool kLean, typename CT, typename P>
+__device__ __forceinline__ float draw_policy_noise(const CT& c, const P& p, uint32_t env_index, uint32_t episode, size_t env,
                                                    bool in_batch, uint32_t step) {
     const int gl = group_lane<G>();
     if (UAV_TAPE(p.step_tape) != nullptr)
@@ -488,8 +542,8 @@ __device__ __forceinline__ int policy_move_toward(float ux, float uy, int gw, in
 //   UAVENV_POLICY_MAX_THROUGHPUT_V2  greedy_agents.py:105-216  collect if an in-range sensor with data has an
 //                                                             acceptable SF, else step toward the best-scored one
 // Python's min()/`score > best` keep the FIRST extremum: the lowest lane among equal keys.
-template <int G>
-__device__ __forceinline__ int policy_action(CRef c, const Sensor& s, const Env& e, bool act, int policy, float zP) {
+template <int G, typename CT>
+__device__ __forceinline__ int policy_action(const CT& c, const Sensor& s, const Env& e, bool act, int policy, float zP) {
     const int gl = group_lane<G>();
     const double det = rssi_deterministic(c, e.ux, e.uy, s.sx, s.sy);
     const bool has = act & (s.b > 0);
@@ -527,8 +581,8 @@ __device__ __forceinline__ int policy_action(CRef c, const Sensor& s, const Env&
     return (collect | (pick == 0ull)) ? 4 : mv;
 }
 
-template <int G, bool kLean, typename P>
-__device__ __forceinline__ void draw_step_noise(CRef c, const P& p, uint32_t env_index, uint32_t episode,
+template <int G, bool kLean, typename CT, typename P>
+__device__ __forceinline__ void draw_step_noise(const CT& c, const P& p, uint32_t env_index, uint32_t episode,
                                                 size_t env, bool in_batch, uint32_t step, bool need_collect, StepNoise& z) {
     const int gl = group_lane<G>();
     z.c2 = z.c3 = 0u; z.zc_ready = true; z.w3 = 0u; z.have_w3 = false;
@@ -563,8 +617,8 @@ __device__ __forceinline__ void finish_zc(StepNoise& z) {   // call under wave-u
 // uav_env.py:400-427 reset (+ iot_sensors.py:305-321, uav.py:241-258; DomainRandEnv.reset
 // dqn.py:301-373 under the flags) for the groups with `rs` set.  Leaves the new episode's sensor
 // registers in `s`, the record in `r`, and returns (zD, zE) of the reset observation.
-template <int G, bool kLean, typename P>
-__device__ __forceinline__ void reset_group(CRef c, const P& p, Sensor& s, UavEnvRecord& r, size_t env,
+template <int G, bool kLean, typename CT, typename P>
+__device__ __forceinline__ void reset_group(const CT& c, const P& p, Sensor& s, UavEnvRecord& r, size_t env,
                                             bool in_batch, bool rs, bool draw_layout, float& zD, float& zE,
                                             uint32_t& w3, bool& have_w3) {
     const int gl = group_lane<G>();
@@ -633,8 +687,8 @@ __device__ __forceinline__ void reset_group(CRef c, const P& p, Sensor& s, UavEn
 
 // dqn.py:375-403 _sample_far_start: rejection-sample a start >= min_start_dist from every sensor,
 // falling back to the furthest candidate.  Candidates from Philox call 4 (lane field = try).
-template <int G>
-__device__ __forceinline__ void far_start(CRef c, const Sensor& s, UavEnvRecord& r, bool act, bool rs) {
+template <int G, typename CT>
+__device__ __forceinline__ void far_start(const CT& c, const Sensor& s, UavEnvRecord& r, bool act, bool rs) {
     double W = (double)r.grid_w, H = (double)r.grid_h;
     float best_x = r.start_x, best_y = r.start_y, best_d = -1.0f;
     bool searching = rs;
@@ -742,14 +796,15 @@ __device__ __forceinline__ int random_action(uint32_t w3) { return (int)(((uint6
 // launch uses "(word & 7) == 4" to spread the collect steps over the SIMDs.  0 = no information.
 __device__ __forceinline__ uint32_t hint_tag(uint32_t episode, uint32_t step) { return 8u | ((step & 0xFFFFu) << 4) | (episode << 20); }
 
-template <int G, bool kLean, bool kRegs = false, typename RecPtr = UavEnvRecord*, typename P = Ptrs, typename A = StepArgs>
-__device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32_t env, bool in_batch,
+template <int G, bool kLean, bool kRegs = false, typename RecPtr = UavEnvRecord*, typename CT = Consts, typename P = Ptrs, typename A = StepArgs>
+__device__ __forceinline__ void step_once(const CT& c, const P& p, const A& a, uint32_t env, bool in_batch,
                                           RecPtr rec, UavEnvRecord* rec_out, Sensor& s, bool& wrote_pos, bool& live, uint32_t& status_or,
                                           int& action_out, uint32_t& next_word, uint32_t hint_word = 0u, size_t row_offset = 0) {
     const int gl = group_lane<G>();
     // outputs of fused rollouts are [K][E][...] blocks: row = k * E + env (k = 0 for the single-step kernel)
     const size_t out = row_offset + env;
     UAV_PHASE(0);
+    UAV_EXIT_AT(0, env);
     Env e = load_env<G>(rec);
     const int n = e.n;
     const bool act = gl < n;
@@ -783,6 +838,7 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
     const bool is_m = (action >= 0) & (action <= 3);
     const uint32_t status_bits = (!is_c & !is_m) ? 1u : 0u;     // uav_env.py:468 ValueError (after ageing)
     UAV_PHASE(1);
+    UAV_EXIT_AT(1, action + e.step + (int)e.episode + (int)e.ux);
 
     // ---- uav_env.py:439-447: step counter, edge-cell bookkeeping on the PRE-move position --------
     e.step += 1;
@@ -808,6 +864,7 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
     }
     const double step_data_loss = gsum<G>(loss);
     UAV_PHASE(2);
+    UAV_EXIT_AT(2, __double2loint(step_data_loss) + __double2loint(s.tx + s.avg) + (int)s.flags + (int)s.sx + (int)s.sy);
 
     double reward = 0.0;
     double bytes_step = 0.0;          // uav_env.py:607 last_step_bytes_collected
@@ -843,6 +900,7 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
     // post-action position) all share it.
     const double det = rssi_deterministic(c, e.ux, e.uy, s.sx, s.sy);
     UAV_PHASE(3);
+    UAV_EXIT_AT(3, (uint32_t)__ballot(det > -80.0) + __double2loint(reward));
 
 #ifdef UAV_ABL_NOCOLLECT     // timing-only ablation build
     const bool any_c = false;
@@ -852,6 +910,7 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
     StepNoise z;
     draw_step_noise<G, kLean>(c, p, e.env_index, e.episode, env, in_batch, step, any_c, z);
     UAV_PHASE(4);
+    UAV_EXIT_AT(4, (uint32_t)__ballot(det + z.zD > -80.0) + (uint32_t)__ballot(z.zE + z.u + z.zA > 0.f) + __double2loint(reward));
 
     // ---- :518-632 collect with Capture-Effect collision handling ---------------------------------
     if (any_c) {
@@ -1003,6 +1062,7 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
     }
     const double reward_unshaped = reward;                                        // :487 total_reward += reward
     UAV_PHASE(5);
+    UAV_EXIT_AT(5, (uint32_t)__ballot(det + z.zD > -80.0) + (uint32_t)__ballot(z.zE + (float)s.b > 0.f) + __double2loint(reward) + visited_cnt);
 
     // ---- observation of the stepped state (side effect: ADR EMA) -------------------------------
     const bool auto_reset = (UAV_FLAGS(c) & UAVENV_FLAG_AUTO_RESET) != 0;
@@ -1028,12 +1088,18 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
             }
             if (in_batch && gl == 0 && a.term_index != nullptr) a.term_index[out] = row;
         }
-        observe<G, kLean>(c, s, n, e.gw, e.gh, e.inv_w, e.inv_h, e.ux, e.uy, e.battery, act, true, det, z.zD, z.zE, dst);   // :488
+        observe<G, kLean>(c, s, n, e.gw, e.gh, e.inv_w, e.inv_h, e.ux, e.uy, e.battery, act, true, det, z.zD, z.zE, dst,
+                          a.write_through != 0);   // :488
     }
 
+    UAV_EXIT_AT(6, (uint32_t)__ballot(s.avg > -80.0) + __double2loint(reward) + visited_cnt + (int)s.flags);
     // ---- epilogue: the cold part of the record (read late on purpose: see struct Env) -----------------
     asm volatile("" ::: "memory");
+#ifdef UAV_ABL_NORELOAD       // timing-only ablation build
+    UavEnvRecord r = {};
+#else
     UavEnvRecord r = load_record(rec);
+#endif
     UAV_PHASE(6);
     if (G == 64 && kRegs) {   // wave-uniform: keep the record in SGPRs (the single-step kernel reads it with scalar loads)
         union { UavEnvRecord r; int w[32]; } u;
@@ -1104,7 +1170,8 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
         if (do_reset) { r.uav_x = r.start_x; r.uav_y = r.start_y; }
         double det0 = rssi_deterministic(c, r.uav_x, r.uav_y, s.sx, s.sy);
         float* dst = (in_batch && a.obs) ? a.obs + out * (size_t)c.obs_dim : nullptr;
-        observe<G, kLean>(c, s, r.num_sensors, r.grid_w, r.grid_h, r.inv_grid_w, r.inv_grid_h, r.uav_x, r.uav_y, r.battery, act, do_reset, det0, zD, zE, dst);
+        observe<G, kLean>(c, s, r.num_sensors, r.grid_w, r.grid_h, r.inv_grid_w, r.inv_grid_h, r.uav_x, r.uav_y, r.battery, act, do_reset, det0, zD, zE, dst,
+                          a.write_through != 0);
         if (UAV_FLAGS(c) & UAVENV_FLAG_PROX_SHAPING) {
             double d0 = dist_nearest_with_data<G>(s, act, r.uav_x, r.uav_y);
             if (do_reset) r.prev_dist_nearest = d0;
@@ -1112,7 +1179,11 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
         wrote_pos |= draw_layout && do_reset;
     }
     if (kRegs) *rec_out = r;
+#ifdef UAV_ABL_NOREC          // timing-only ablation build
+    else if (gl == 0 && reward == -12345.0) {
+#else
     else if (gl == 0) {
+#endif
 #ifndef UAV_ABL_FULLREC
         // words 24..31 (grid height, sensor count, env index, status, reciprocals) only change at a reset or on an
         // invalid action: without either (decided per wave when the group is the wave) the first 96 bytes are all there is
@@ -1161,7 +1232,7 @@ __device__ __forceinline__ void step_once(CRef c, const P& p, const A& a, uint32
 // ---------------------------------------------------------------------------------------------
 // step kernel: one launch = one step() of every environment
 // ---------------------------------------------------------------------------------------------
-template <int G, bool kLean, int kWaves>
+template <int G, bool kLean, int kWaves, bool kDefC>
 __global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kernel(
         // The first seven arguments repeat fields of the two structs: they are the pointers the first loads of a wave
         // need, and as leading scalar arguments they arrive PRELOADED in SGPRs with the wave launch (gfx950 kernarg
@@ -1179,7 +1250,7 @@ __global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kerne
     const SensorBase sb{sensor_base, lanes};
     const int32_t num_envs = (int32_t)(uint32_t)balance_and_envs;
     const bool balance = (balance_and_envs >> 32) != 0ull;
-    UAV_CONSTS(cptr);
+    decltype(auto) c = ConstsSel<kDefC>::make(*(const __attribute__((address_space(4))) Consts*)(cptr));
 #ifdef UAVENV_STAMPS
     const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1292,7 +1363,7 @@ __global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kerne
                                               live, status_or, action, next_word, hint_word);
     } else
         step_once<G, kLean>(c, p, a, env, in_batch, rec_base + env, rec_base + env, s, wrote_pos, live, status_or, action, next_word, hint_word);
-    store_sensor<G>(sb, idx, s, wrote_pos, live, tx0, lost0);
+    store_sensor<G>(sb, idx, s, wrote_pos, live, tx0, lost0, a.write_through != 0);
     if (gl == 0 && status_or) atomicOr(p.status, status_or);
 #ifdef UAVENV_STAMPS
     if (p.stamps != nullptr && (threadIdx.x & 63u) == 0) {
@@ -1311,7 +1382,7 @@ __global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kerne
 // whole launch; every step still writes its observation / reward / done block ([K][E][...] layout, e.g. K consecutive
 // slots of a replay ring), so the result is bit-identical to K single-step launches.
 // ---------------------------------------------------------------------------------------------
-template <int G, bool kLean>
+template <int G, bool kLean, bool kDefC>
 __global__ __launch_bounds__(kSmallBlockThreads, (G == 64 ? 4 : 2)) void uav_rollout_kernel(const Consts* cptr, Ptrs p_in, StepArgs a_in,
                                                                                      int32_t num_steps) {
     // as in the step kernel, the argument structs are read in place from the kernarg segment (constant address space)
@@ -1320,7 +1391,6 @@ __global__ __launch_bounds__(kSmallBlockThreads, (G == 64 ? 4 : 2)) void uav_rol
     KA ka0 = (KA)__builtin_amdgcn_kernarg_segment_ptr();
     const __attribute__((address_space(4))) Ptrs& p = *(const __attribute__((address_space(4))) Ptrs*)(ka0 + offsetof(Kernargs, p));
     const __attribute__((address_space(4))) StepArgs& a = *(const __attribute__((address_space(4))) StepArgs*)(ka0 + offsetof(Kernargs, a));
-    UAV_CONSTS(cptr);
     const int gl = group_lane<G>();
     const uint32_t grp = threadIdx.x / G;
     const uint32_t env = blockIdx.x * (kSmallBlockThreads / G) + uni<G>((int)grp);
@@ -1340,7 +1410,7 @@ __global__ __launch_bounds__(kSmallBlockThreads, (G == 64 ? 4 : 2)) void uav_rol
         // out of the loop and the SGPR file spills into VGPR lanes (and those into scratch).
         const Consts* cp = cptr;
         asm volatile("" : "+s"(cp));
-        CRef ck = *(const __attribute__((address_space(4))) Consts*)(cp);
+        decltype(auto) ck = ConstsSel<kDefC>::make(*(const __attribute__((address_space(4))) Consts*)(cp));
         KA ka = ka0;                              // same for the argument structs
         asm volatile("" : "+s"(ka));
         const __attribute__((address_space(4))) Ptrs& pk = *(const __attribute__((address_space(4))) Ptrs*)(ka + offsetof(Kernargs, p));
@@ -1349,7 +1419,7 @@ __global__ __launch_bounds__(kSmallBlockThreads, (G == 64 ? 4 : 2)) void uav_rol
         // structs stay untouched (no per-step copies of nine pointers competing for SGPRs)
         step_once<G, kLean, true>(ck, pk, ak, env, in_batch, &rr, &rr, s, wrote_pos, live, status_or, action, carried_word, carried_word, (size_t)k * E);
     }
-    store_sensor<G>(p, idx, s, wrote_pos, live, tx0, lost0);
+    store_sensor<G>(p, idx, s, wrote_pos, live, tx0, lost0, a.write_through != 0);
     if (gl == 0) p.rec[env] = rr;
     if (gl == 0 && status_or) atomicOr(p.status, status_or);
 }
@@ -1475,7 +1545,8 @@ hipError_t launch_reset(int Gw, int padded_envs, const Consts& c, const Consts* 
 }
 bool step_uses_big_workgroups(int Gw, int padded_envs) { return (long)padded_envs * Gw / 64 >= 16L * 256L; }
 
-hipError_t launch_step(int Gw, int padded_envs, const Consts& c, const Consts* dc, const Ptrs& p, const StepArgs& a, hipStream_t s) {
+hipError_t launch_step(int Gw, int padded_envs, const Consts& c, const Consts* dc, const Ptrs& p, const StepArgs& a, bool default_consts,
+                       hipStream_t s) {
     // 16-wave workgroups (one per CU, collect steps dealt over its SIMDs) once every CU gets at least that many waves;
     // smaller batches use 4-wave workgroups so that they still spread over all CUs
     const long waves = (long)padded_envs * Gw / 64;
@@ -1483,23 +1554,27 @@ hipError_t launch_step(int Gw, int padded_envs, const Consts& c, const Consts* d
     const int wg_waves = big ? kBlockThreads / 64 : kSmallBlockThreads / 64;
     dim3 block(wg_waves * 64), grid((unsigned)(waves / wg_waves));
     const uint64_t be = ((uint64_t)(uint32_t)a.balance << 32) | (uint64_t)(uint32_t)a.num_envs;
-#define UAV_STEP_LAUNCH(LEAN, WV) uav_step_kernel<G, LEAN, WV><<<grid, block, lds_bytes(Gw, c), s>>>( \
+#define UAV_STEP_LAUNCH(LEAN, WV, DEFC) uav_step_kernel<G, LEAN, WV, DEFC><<<grid, block, lds_bytes(Gw, c), s>>>( \
         dc, p.sensor_base, p.lanes, p.rec, a.hint_in, a.actions, be, p, a)
-    if (lean_ok(c, p, a)) {
-        if (big) { UAV_DISPATCH_G(Gw, (UAV_STEP_LAUNCH(true, kBlockThreads / 64))); }
-        else { UAV_DISPATCH_G(Gw, (UAV_STEP_LAUNCH(true, kSmallBlockThreads / 64))); }
+    if (lean_ok(c, p, a) && default_consts) {       // the reference configuration: constants as instruction literals
+        if (big) { UAV_DISPATCH_G(Gw, (UAV_STEP_LAUNCH(true, kBlockThreads / 64, true))); }
+        else { UAV_DISPATCH_G(Gw, (UAV_STEP_LAUNCH(true, kSmallBlockThreads / 64, true))); }
+    } else if (lean_ok(c, p, a)) {
+        if (big) { UAV_DISPATCH_G(Gw, (UAV_STEP_LAUNCH(true, kBlockThreads / 64, false))); }
+        else { UAV_DISPATCH_G(Gw, (UAV_STEP_LAUNCH(true, kSmallBlockThreads / 64, false))); }
     } else {
-        if (big) { UAV_DISPATCH_G(Gw, (UAV_STEP_LAUNCH(false, kBlockThreads / 64))); }
-        else { UAV_DISPATCH_G(Gw, (UAV_STEP_LAUNCH(false, kSmallBlockThreads / 64))); }
+        if (big) { UAV_DISPATCH_G(Gw, (UAV_STEP_LAUNCH(false, kBlockThreads / 64, false))); }
+        else { UAV_DISPATCH_G(Gw, (UAV_STEP_LAUNCH(false, kSmallBlockThreads / 64, false))); }
     }
 #undef UAV_STEP_LAUNCH
     return hipGetLastError();
 }
 hipError_t launch_rollout(int Gw, int padded_envs, const Consts& c, const Consts* dc, const Ptrs& p, const StepArgs& a,
-                          int32_t num_steps, hipStream_t s) {
+                          int32_t num_steps, bool default_consts, hipStream_t s) {
     dim3 block(kSmallBlockThreads), grid((unsigned)(padded_envs / (kSmallBlockThreads / Gw)));
-    if (lean_ok(c, p, a)) { UAV_DISPATCH_G(Gw, (uav_rollout_kernel<G, true><<<grid, block, lds_bytes(Gw, c), s>>>(dc, p, a, num_steps))); }
-    else { UAV_DISPATCH_G(Gw, (uav_rollout_kernel<G, false><<<grid, block, lds_bytes(Gw, c), s>>>(dc, p, a, num_steps))); }
+    if (lean_ok(c, p, a) && default_consts) { UAV_DISPATCH_G(Gw, (uav_rollout_kernel<G, true, true><<<grid, block, lds_bytes(Gw, c), s>>>(dc, p, a, num_steps))); }
+    else if (lean_ok(c, p, a)) { UAV_DISPATCH_G(Gw, (uav_rollout_kernel<G, true, false><<<grid, block, lds_bytes(Gw, c), s>>>(dc, p, a, num_steps))); }
+    else { UAV_DISPATCH_G(Gw, (uav_rollout_kernel<G, false, false><<<grid, block, lds_bytes(Gw, c), s>>>(dc, p, a, num_steps))); }
     return hipGetLastError();
 }
 hipError_t launch_dump_noise(int Gw, int padded_envs, const Consts& c, const Consts* dc, const Ptrs& p, float* step_tape,
