@@ -81,6 +81,8 @@ struct DefaultConsts {
         : m(k), seed(k.seed), max_steps(k.max_steps), fps(k.fps), obs_dim(k.obs_dim), obs_slots(k.obs_slots), use_ema(k.use_ema),
           max_tries(k.max_tries), n_grid_choices(k.n_grid_choices), flags(k.flags), gw(k.gw), gh(k.gh), inv_small(k.inv_small) {}
 };
+template <typename T> constexpr bool kIsDefaultConsts = false;
+template <> constexpr bool kIsDefaultConsts<DefaultConsts> = true;
 template <bool kDefC> struct ConstsSel;
 template <> struct ConstsSel<false> { static __device__ __forceinline__ CRef make(CRef k) { return k; } };
 template <> struct ConstsSel<true> { static __device__ __forceinline__ DefaultConsts make(CRef k) { return DefaultConsts(k); } };
@@ -303,6 +305,11 @@ template <typename CT> __device__ __forceinline__ void adr_update(const CT& c, d
     flags = (flags & ~kSfMask) | sf | kAvgValid;
 }
 
+// iot_sensors.py:211 the SNR sigmoid.  Needed only when the lottery uniform falls into a 2e-9-wide band (see the collect
+// block): kept out of line so that the exponential's two dozen polynomial constants are not hoisted into registers
+// around the rollout kernel's step loop (they were its scratch spills).
+__device__ __attribute__((noinline, cold)) double sigmoid_rare(double x) { return 1.0 / (1.0 + exp(-x)); }
+
 // x / y for a divisor whose correctly rounded reciprocal `inv` is known: Markstein's sequence (one product,
 // two fma; 3 instructions instead of the 12 of an IEEE float64 division).  q0 = RN(x*inv) is within one ulp,
 // the fma residual is exact, and the corrected quotient equals RN(x / y) (checked exhaustively against true
@@ -406,10 +413,10 @@ template <int G, typename P> __device__ __forceinline__ void load_sensor(const P
     s.flags = sensor_at<uint32_t>(p, kOffFlags, idx);
 }
 // Write back what the step can have changed: nothing for lanes beyond the environment's sensor count (`live` false:
-// their state never changes), `tx` only if some lane of the wave collected or reset (compared with the loaded value),
-// `lost` only if some buffer overflowed or reset.  Cuts the write traffic by about a third.
+// their state never changes), `tx` only if some lane of the wave collected or reset (bit 0 of `dirty`, set where the
+// step touches it), `lost` only if some buffer overflowed or reset (bit 1).  Cuts the write traffic by about a third.
 template <int G, typename P> __device__ __forceinline__ void store_sensor(const P& p, uint32_t idx, const Sensor& s, bool with_pos,
-                                                                          bool live, double tx0, double lost0, bool wt) {
+                                                                          bool live, uint32_t dirty, bool wt) {
 #ifdef UAV_ABL_NOSTATE        // timing-only ablation build
     if (s.b != -1.0) return;
 #endif
@@ -419,8 +426,8 @@ template <int G, typename P> __device__ __forceinline__ void store_sensor(const 
         store_wt(&sensor_at<double>(p, kOffAvg, idx), s.avg, wt);
         store_wt(&sensor_at<uint32_t>(p, kOffFlags, idx), s.flags, wt);
     }
-    if (__any(live & (s.tx != tx0)) && live) store_wt(&sensor_at<double>(p, kOffTx, idx), s.tx, wt);
-    if (__any(live & (s.lost != lost0)) && live) store_wt(&sensor_at<double>(p, kOffLost, idx), s.lost, wt);
+    if (__any(live & ((dirty & 1u) != 0u)) && live) store_wt(&sensor_at<double>(p, kOffTx, idx), s.tx, wt);
+    if (__any(live & ((dirty & 2u) != 0u)) && live) store_wt(&sensor_at<double>(p, kOffLost, idx), s.lost, wt);
 }
 // unconditional form (initialisation, reset kernel)
 template <int G, typename P> __device__ __forceinline__ void store_sensor(const P& p, uint32_t idx, const Sensor& s, bool with_pos) {
@@ -798,7 +805,7 @@ __device__ __forceinline__ uint32_t hint_tag(uint32_t episode, uint32_t step) { 
 
 template <int G, bool kLean, bool kRegs = false, typename RecPtr = UavEnvRecord*, typename CT = Consts, typename P = Ptrs, typename A = StepArgs>
 __device__ __forceinline__ void step_once(const CT& c, const P& p, const A& a, uint32_t env, bool in_batch,
-                                          RecPtr rec, UavEnvRecord* rec_out, Sensor& s, bool& wrote_pos, bool& live, uint32_t& status_or,
+                                          RecPtr rec, UavEnvRecord* rec_out, Sensor& s, bool& wrote_pos, bool& live, uint32_t& dirty, uint32_t& status_or,
                                           int& action_out, uint32_t& next_word, uint32_t hint_word = 0u, size_t row_offset = 0) {
     const int gl = group_lane<G>();
     // outputs of fused rollouts are [K][E][...] blocks: row = k * E + env (k = 0 for the single-step kernel)
@@ -860,6 +867,7 @@ __device__ __forceinline__ void step_once(const CT& c, const P& p, const A& a, u
         s.gen = act ? s.gen + new_data : s.gen;
         s.b = act ? (over ? c.bmax : potential) : s.b;
         s.lost = (act & over) ? s.lost + l : s.lost;
+        dirty |= (act & over) ? 2u : 0u;
         loss = act ? l : 0.0;
     }
     const double step_data_loss = gsum<G>(loss);
@@ -941,10 +949,12 @@ __device__ __forceinline__ void step_once(const CT& c, const P& p, const A& a, u
             const bool in_rng = !(rssi < c.thr);
             const bool sure_yes = (x > 20.0) & ((c.p_cycle * (1.0 - 2.2e-9)) > u);
             const bool sure_no = !(c.p_cycle > u);
-            const bool need_exp = has & in_rng & !sure_yes & !sure_no;
+            // (default constants: in range means rssi >= -85 = noise floor + 20 and every required SNR is <= -6, so x >= 26 and the
+            // exponential can never be needed; the generic kernels keep the exact path for other thresholds)
+            const bool need_exp = kIsDefaultConsts<CT> ? false : (has & in_rng & !sure_yes & !sure_no);
             bool att = sure_yes;
             if (__any(need_exp)) {
-                const double p_link = 1.0 / (1.0 + exp(-x));
+                const double p_link = sigmoid_rare(x);
                 att = need_exp ? ((p_link * c.p_cycle) > u) : att;
             }
             attempt = has & in_rng & att;                                       // :549
@@ -985,6 +995,7 @@ __device__ __forceinline__ void step_once(const CT& c, const P& p, const A& a, u
             bytes = take ? by : 0.0;
             s.b = take ? s.b - by : s.b;
             s.tx = take ? s.tx + by : s.tx;
+            dirty |= take ? 1u : 0u;
             got = take & (by > 0);
             s.flags |= got ? kDataCollected : 0u;
         }
@@ -1177,6 +1188,7 @@ __device__ __forceinline__ void step_once(const CT& c, const P& p, const A& a, u
             if (do_reset) r.prev_dist_nearest = d0;
         }
         wrote_pos |= draw_layout && do_reset;
+        dirty |= do_reset ? 3u : 0u;                    // the reset zeroed tx / lost
     }
     if (kRegs) *rec_out = r;
 #ifdef UAV_ABL_NOREC          // timing-only ablation build
@@ -1346,9 +1358,8 @@ __global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kerne
     const bool in_batch = env < (uint32_t)num_envs;
     Sensor s;
     load_sensor<G>(sb, idx, s);
-    const double tx0 = s.tx, lost0 = s.lost;
     bool wrote_pos = false, live = false;
-    uint32_t status_or = 0u;
+    uint32_t status_or = 0u, dirty = 0u;
     int action = 0;
     uint32_t next_word = 0u;
     uint32_t hint_word = 0u;
@@ -1360,10 +1371,10 @@ __global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kerne
     if (G == 64) {
         typedef const __attribute__((address_space(4))) UavEnvRecord* ScalarRec;
         step_once<G, kLean, false, ScalarRec>(c, p, a, env, in_batch, (ScalarRec)(rec_base + env), rec_base + env, s, wrote_pos,
-                                              live, status_or, action, next_word, hint_word);
+                                              live, dirty, status_or, action, next_word, hint_word);
     } else
-        step_once<G, kLean>(c, p, a, env, in_batch, rec_base + env, rec_base + env, s, wrote_pos, live, status_or, action, next_word, hint_word);
-    store_sensor<G>(sb, idx, s, wrote_pos, live, tx0, lost0, a.write_through != 0);
+        step_once<G, kLean>(c, p, a, env, in_batch, rec_base + env, rec_base + env, s, wrote_pos, live, dirty, status_or, action, next_word, hint_word);
+    store_sensor<G>(sb, idx, s, wrote_pos, live, dirty, a.write_through != 0);
     if (gl == 0 && status_or) atomicOr(p.status, status_or);
 #ifdef UAVENV_STAMPS
     if (p.stamps != nullptr && (threadIdx.x & 63u) == 0) {
@@ -1398,10 +1409,9 @@ __global__ __launch_bounds__(kSmallBlockThreads, (G == 64 ? 4 : 2)) void uav_rol
     const bool in_batch = env < (uint32_t)a.num_envs;
     Sensor s;
     load_sensor<G>(p, idx, s);
-    const double tx0 = s.tx, lost0 = s.lost;
     UavEnvRecord rr = p.rec[env];
     bool wrote_pos = false, live = false;
-    uint32_t status_or = 0u;
+    uint32_t status_or = 0u, dirty = 0u;
     const size_t E = (size_t)a.num_envs;
     uint32_t carried_word = 0u;      // the random policy's next action, handed from step to step (0: draw it)
     for (int k = 0; k < num_steps; k++) {
@@ -1417,9 +1427,9 @@ __global__ __launch_bounds__(kSmallBlockThreads, (G == 64 ? 4 : 2)) void uav_rol
         const __attribute__((address_space(4))) StepArgs& ak = *(const __attribute__((address_space(4))) StepArgs*)(ka + offsetof(Kernargs, a));
         // every step writes block k of the [K][E][...] outputs: the row offset k * E goes to step_once, the argument
         // structs stay untouched (no per-step copies of nine pointers competing for SGPRs)
-        step_once<G, kLean, true>(ck, pk, ak, env, in_batch, &rr, &rr, s, wrote_pos, live, status_or, action, carried_word, carried_word, (size_t)k * E);
+        step_once<G, kLean, true>(ck, pk, ak, env, in_batch, &rr, &rr, s, wrote_pos, live, dirty, status_or, action, carried_word, carried_word, (size_t)k * E);
     }
-    store_sensor<G>(p, idx, s, wrote_pos, live, tx0, lost0, a.write_through != 0);
+    store_sensor<G>(p, idx, s, wrote_pos, live, dirty, a.write_through != 0);
     if (gl == 0) p.rec[env] = rr;
     if (gl == 0 && status_or) atomicOr(p.status, status_or);
 }
