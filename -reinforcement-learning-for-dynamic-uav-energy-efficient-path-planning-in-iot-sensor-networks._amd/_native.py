@@ -13,7 +13,7 @@ _D = C.c_double
 
 FLAG_RANDOM_LAYOUT, FLAG_FAR_START, FLAG_PROX_SHAPING, FLAG_JAIN_BONUS, FLAG_AUTO_RESET = 1, 2, 4, 8, 16
 
-(F_POS_X, F_POS_Y, F_BUFFER, F_GEN, F_TX, F_LOST, F_AVG_RSSI, F_FLAGS, F_RECORD, F_EPISODE_STATS) = range(10)
+(F_POS_X, F_POS_Y, F_BUFFER, F_GEN, F_TX, F_LOST, F_AVG_RSSI, F_FLAGS, F_RECORD, F_EPISODE_STATS, F_TERM_RECORD, F_TERM_SENSORS) = range(12)
 
 E_INVALID, E_HIP, E_ACTION, E_ALLOC = -1, -2, -3, -4
 POLICY_ACTIONS, POLICY_RANDOM, POLICY_NEAREST, POLICY_MAX_THROUGHPUT_V2 = 0, 1, 2, 3
@@ -74,7 +74,7 @@ EXPORTS = [
     "uavenv_abi_version", "uavenv_default_config", "uavenv_obs_dim", "uavenv_create", "uavenv_destroy",
     "uavenv_last_error", "uavenv_num_envs", "uavenv_lane_stride", "uavenv_env_obs_dim", "uavenv_set_env_params",
     "uavenv_set_positions", "uavenv_set_seed", "uavenv_set_grid_choices", "uavenv_set_noise_tape",
-    "uavenv_dump_noise", "uavenv_reset", "uavenv_step", "uavenv_step_random", "uavenv_step_policy", "uavenv_rollout", "uavenv_frame_stack", "uavenv_set_terminal_pool", "uavenv_set_aux_output", "uavenv_attention_weight_floats", "uavenv_attention_features", "uavenv_get_state",
+    "uavenv_dump_noise", "uavenv_reset", "uavenv_step", "uavenv_step_random", "uavenv_step_policy", "uavenv_rollout", "uavenv_frame_stack", "uavenv_set_terminal_pool", "uavenv_set_aux_output", "uavenv_enable_terminal_snapshot", "uavenv_attention_weight_floats", "uavenv_attention_features", "uavenv_get_state",
     "uavenv_set_state", "uavenv_state_bytes", "uavenv_reset_host", "uavenv_step_host", "uavenv_time_steps",
 ]
 
@@ -119,6 +119,7 @@ def lib():
         "uavenv_rollout": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
         "uavenv_set_terminal_pool": (C.c_int, [vp, vp, i32, vp, vp]),
         "uavenv_set_aux_output": (C.c_int, [vp, vp, i32]),
+        "uavenv_enable_terminal_snapshot": (C.c_int, [vp, i32]),
         "uavenv_attention_weight_floats": (C.c_int, [i32]),
         "uavenv_attention_features": (C.c_int, [vp, vp, vp, i32, i32, vp]),
         "uavenv_frame_stack": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),

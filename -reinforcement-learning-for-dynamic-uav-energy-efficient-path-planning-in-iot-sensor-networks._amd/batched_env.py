@@ -83,11 +83,15 @@ class BatchedUAVEnv:
         self.num_sensors = cfg.num_sensors
         E, D = self.num_envs, self.obs_dim
         dev = self.device
-        self.obs = torch.zeros(E, D, dtype=torch.float32, device=dev)
+        # what a host caller wants back after every step -- observation, float32 reward, done flag -- lives in ONE
+        # allocation, so that the numpy-returning adapters move it with a single device-to-host copy (vec_env.py)
+        nb = E * D * 4 + E * 4 + E
+        self.out_block = torch.zeros((nb + 15) // 16 * 16, dtype=torch.uint8, device=dev)
+        self.obs = self.out_block[:E * D * 4].view(torch.float32).view(E, D)
+        self.reward32 = self.out_block[E * D * 4:E * D * 4 + E * 4].view(torch.float32)
+        self.done = self.out_block[E * D * 4 + E * 4:E * D * 4 + E * 4 + E]
         self.terminal_obs = torch.zeros(E, D, dtype=torch.float32, device=dev)
         self.reward = torch.zeros(E, dtype=torch.float64, device=dev)
-        self.reward32 = torch.zeros(E, dtype=torch.float32, device=dev)
-        self.done = torch.zeros(E, dtype=torch.uint8, device=dev)
         self.actions_taken = torch.zeros(E, dtype=torch.int32, device=dev)
         self._tapes = (None, None)
         if sensor_positions is not None:
@@ -168,6 +172,20 @@ class BatchedUAVEnv:
             assert cap >= 1 and aux.numel() == cap * 4 * self.num_envs, tuple(aux.shape)
         self._aux = aux
         N.check(self.L.uavenv_set_aux_output(self._h, self._p(aux), cap), self._h)
+
+    def enable_terminal_snapshot(self, enable=True):
+        """Keep, for every environment that ends an episode, the state its terminal step's `info` is made of
+        (uavenv_enable_terminal_snapshot): read it with `terminal_snapshot(indices)`."""
+        N.check(self.L.uavenv_enable_terminal_snapshot(self._h, 1 if enable else 0), self._h)
+        self._term_snapshot = bool(enable)
+
+    def terminal_snapshot(self, indices):
+        """(records [k] structured, sensors [k, 3, lane_stride] float64 = buffer / generated / transmitted) of the last
+        terminal step of the environments `indices`."""
+        idx = torch.as_tensor(np.asarray(indices, np.int64), device=self.device)
+        rec = self.get_state(N.F_TERM_RECORD)[idx].cpu().numpy().view(N.record_dtype()).reshape(len(idx))
+        sens = self.get_state(N.F_TERM_SENSORS).view(self.num_envs, 3, self.lane_stride)[idx].cpu().numpy()
+        return rec, sens
 
     def dump_noise(self):
         E, G = self.num_envs, self.lane_stride
@@ -255,7 +273,8 @@ class BatchedUAVEnv:
             out["actions"] = actions
         if with_terminal:
             out["terminal_obs"] = term
-        self.obs = obs[K - 1] if obs_out is None else self.obs
+        if obs_out is None:
+            self.obs.copy_(obs[K - 1])
         return out
 
     def time_steps(self, steps):
@@ -276,13 +295,14 @@ class BatchedUAVEnv:
     # ---- state access -------------------------------------------------------------------------
     _FIELD_DTYPES = {N.F_POS_X: torch.float32, N.F_POS_Y: torch.float32, N.F_BUFFER: torch.float64,
                      N.F_GEN: torch.float64, N.F_TX: torch.float64, N.F_LOST: torch.float64,
-                     N.F_AVG_RSSI: torch.float64, N.F_FLAGS: torch.int32}
+                     N.F_AVG_RSSI: torch.float64, N.F_FLAGS: torch.int32, N.F_TERM_SENSORS: torch.float64}
 
     def get_state(self, field):
         """Device copy of one state field: [E, lane_stride] tensor (or raw bytes [E, 128] for records)."""
         nbytes = self.L.uavenv_state_bytes(self._h, field)
         if field in self._FIELD_DTYPES:
-            t = torch.empty(self.num_envs, self.lane_stride, dtype=self._FIELD_DTYPES[field], device=self.device)
+            cols = self.lane_stride * (3 if field == N.F_TERM_SENSORS else 1)
+            t = torch.empty(self.num_envs, cols, dtype=self._FIELD_DTYPES[field], device=self.device)
         else:
             t = torch.empty(self.num_envs, nbytes // self.num_envs, dtype=torch.uint8, device=self.device)
         N.check(self.L.uavenv_get_state(self._h, field, self._p(t), nbytes, 1, self._stream()), self._h)

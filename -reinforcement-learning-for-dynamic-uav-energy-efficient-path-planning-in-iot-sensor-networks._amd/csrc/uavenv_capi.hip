@@ -26,12 +26,16 @@ struct UavEnv {
     uint32_t env_index_base = 0;
     void* block = nullptr;          // one hipMalloc holding every state array
     size_t block_bytes = 0;
-    // host-staging buffers for the *_host convenience entry points
+    // staging for the *_host convenience entry points: ONE device block [obs | reward | done | pad | terminal obs] and a
+    // pinned host mirror of it, so that a step moves its results with a single device-to-host transfer
     int32_t* h_actions_dev = nullptr; float* h_obs_dev = nullptr; double* h_rew_dev = nullptr;
     uint8_t* h_done_dev = nullptr; float* h_term_dev = nullptr; uint8_t* h_mask_dev = nullptr;
+    char* h_block_dev = nullptr; char* h_block_pin = nullptr; int32_t* h_actions_pin = nullptr;
+    size_t h_off_rew = 0, h_off_done = 0, h_off_term = 0, h_block_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float* term_pool = nullptr; uint32_t* term_counter = nullptr; int32_t* term_index = nullptr; int32_t term_rows = 0;
     float* aux_out = nullptr; int32_t aux_capacity = 0;
+    void* term_block = nullptr;     // terminal snapshot buffers (uavenv_enable_terminal_snapshot)
     uint32_t* hints = nullptr;      // [2][padded_envs] scheduling hints of the random-policy step (StepArgs::balance)
     int hint_parity = 0;
     bool balance = true;            // UAVENV_NO_BALANCE=1 in the environment keeps the home mapping (A/B timing)
@@ -83,6 +87,7 @@ static void* field_ptr(UavEnv* e, int field) {
         case UAVENV_F_TX: return sb + kOffTx * S;          case UAVENV_F_LOST: return sb + kOffLost * S;
         case UAVENV_F_AVG_RSSI: return sb + kOffAvg * S;   case UAVENV_F_FLAGS: return sb + kOffFlags * S;
         case UAVENV_F_RECORD: return e->ptrs.rec;          case UAVENV_F_EPISODE_STATS: return e->ptrs.stats;
+        case UAVENV_F_TERM_RECORD: return e->ptrs.term_rec; case UAVENV_F_TERM_SENSORS: return e->ptrs.term_sensors;
         default: return nullptr;
     }
 }
@@ -90,6 +95,8 @@ extern "C" size_t uavenv_state_bytes(const UavEnv* e, int32_t field) {
     if (!e) return 0;
     if (field == UAVENV_F_RECORD) return (size_t)e->num_envs * sizeof(UavEnvRecord);
     if (field == UAVENV_F_EPISODE_STATS) return (size_t)e->num_envs * sizeof(UavEnvEpisodeStats);
+    if (field == UAVENV_F_TERM_RECORD) return (size_t)e->num_envs * sizeof(UavEnvRecord);
+    if (field == UAVENV_F_TERM_SENSORS) return (size_t)e->num_envs * 3u * (size_t)e->G * sizeof(double);
     return (size_t)e->num_envs * (size_t)e->G * field_elem_bytes(field);
 }
 
@@ -143,6 +150,7 @@ extern "C" int uavenv_create(const UavEnvConfig* cfg, int32_t num_envs, uint32_t
     e->hints = (uint32_t*)(base + o_h);
     { const char* nb = getenv("UAVENV_NO_BALANCE"); e->balance = !(nb && nb[0] == '1'); }
     e->ptrs.step_tape = nullptr; e->ptrs.reset_tape = nullptr; e->ptrs.stamps = nullptr;
+    e->ptrs.term_rec = nullptr; e->ptrs.term_sensors = nullptr;
     st = hipMemset(e->block, 0, off);
     if (st != hipSuccess) return bail(UAVENV_E_HIP, std::string("hipMemset: ") + hipGetErrorString(st));
     if (st == hipSuccess) st = hipMemcpy(e->dev_consts, &e->consts, sizeof(Consts), hipMemcpyHostToDevice);
@@ -160,8 +168,11 @@ extern "C" int uavenv_create(const UavEnvConfig* cfg, int32_t num_envs, uint32_t
 extern "C" int uavenv_destroy(UavEnv* e) {
     if (!e) return UAVENV_OK;
     if (e->block) (void)hipFree(e->block);
-    void* tmp[] = {e->h_actions_dev, e->h_obs_dev, e->h_rew_dev, e->h_done_dev, e->h_term_dev, e->h_mask_dev};
+    if (e->term_block) (void)hipFree(e->term_block);
+    void* tmp[] = {e->h_actions_dev, e->h_block_dev, e->h_mask_dev};
     for (void* t : tmp) if (t) (void)hipFree(t);
+    if (e->h_block_pin) (void)hipHostFree(e->h_block_pin);
+    if (e->h_actions_pin) (void)hipHostFree(e->h_actions_pin);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     delete e;
@@ -300,6 +311,24 @@ extern "C" int uavenv_set_terminal_pool(UavEnv* e, float* pool_dev, int32_t rows
     return UAVENV_OK;
 }
 
+extern "C" int uavenv_enable_terminal_snapshot(UavEnv* e, int32_t enable) {
+    if (!e) return UAVENV_E_INVALID;
+    HIP_TRY(e, hipDeviceSynchronize());                // launches in flight may still write the old buffers
+    if (!enable) {
+        if (e->term_block) (void)hipFree(e->term_block);
+        e->term_block = nullptr; e->ptrs.term_rec = nullptr; e->ptrs.term_sensors = nullptr;
+        return UAVENV_OK;
+    }
+    if (e->term_block) return UAVENV_OK;
+    const size_t P = (size_t)e->padded_envs;
+    const size_t rec_bytes = (P * sizeof(UavEnvRecord) + 255) & ~(size_t)255, sens_bytes = P * 3u * (size_t)e->G * sizeof(double);
+    if (hipMalloc(&e->term_block, rec_bytes + sens_bytes) != hipSuccess) { e->term_block = nullptr; return fail(e, UAVENV_E_ALLOC, "terminal snapshot: out of device memory"); }
+    HIP_TRY(e, hipMemset(e->term_block, 0, rec_bytes + sens_bytes));
+    e->ptrs.term_rec = (UavEnvRecord*)e->term_block;
+    e->ptrs.term_sensors = (double*)((char*)e->term_block + rec_bytes);
+    return UAVENV_OK;
+}
+
 extern "C" int uavenv_set_aux_output(UavEnv* e, float* aux_out_dev, int32_t capacity_steps) {
     if (!e) return UAVENV_E_INVALID;
     if (aux_out_dev != nullptr && capacity_steps < 1) return fail(e, UAVENV_E_INVALID, "aux output needs capacity_steps >= 1");
@@ -322,7 +351,8 @@ extern "C" int uavenv_frame_stack(float* stacked_dev, const float* obs_dev, cons
 extern "C" int uavenv_get_state(UavEnv* e, int32_t field, void* dst, size_t bytes, int32_t dst_on_device, void* stream) {
     if (!e || !dst) return UAVENV_E_INVALID;
     void* src = field_ptr(e, field);
-    if (!src) return fail(e, UAVENV_E_INVALID, "unknown state field");
+    if (!src) return fail(e, UAVENV_E_INVALID, field == UAVENV_F_TERM_RECORD || field == UAVENV_F_TERM_SENSORS
+                                                   ? "terminal snapshot is not enabled (uavenv_enable_terminal_snapshot)" : "unknown state field");
     if (bytes != uavenv_state_bytes(e, field)) return fail(e, UAVENV_E_INVALID, "state field size mismatch");
     HIP_TRY(e, hipMemcpyAsync(dst, src, bytes, dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, (hipStream_t)stream));
     if (!dst_on_device) HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream));
@@ -342,14 +372,18 @@ extern "C" int uavenv_set_state(UavEnv* e, int32_t field, const void* src, size_
 }
 
 static int ensure_host_staging(UavEnv* e) {
-    if (e->h_obs_dev) return UAVENV_OK;
-    size_t E = (size_t)e->num_envs, D = (size_t)e->consts.obs_dim;
+    if (e->h_block_dev) return UAVENV_OK;
+    const size_t E = (size_t)e->num_envs, D = (size_t)e->consts.obs_dim;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    e->h_off_rew = al(E * D * 4); e->h_off_done = e->h_off_rew + al(E * 8); e->h_off_term = e->h_off_done + al(E + 16);   // + the status word
+    e->h_block_bytes = e->h_off_term + al(E * D * 4);
     HIP_TRY(e, hipMalloc((void**)&e->h_actions_dev, E * 4));
-    HIP_TRY(e, hipMalloc((void**)&e->h_obs_dev, E * D * 4));
-    HIP_TRY(e, hipMalloc((void**)&e->h_rew_dev, E * 8));
-    HIP_TRY(e, hipMalloc((void**)&e->h_done_dev, E));
-    HIP_TRY(e, hipMalloc((void**)&e->h_term_dev, E * D * 4));
     HIP_TRY(e, hipMalloc((void**)&e->h_mask_dev, E));
+    HIP_TRY(e, hipMalloc((void**)&e->h_block_dev, e->h_block_bytes));
+    HIP_TRY(e, hipHostMalloc((void**)&e->h_block_pin, e->h_block_bytes, hipHostMallocDefault));
+    HIP_TRY(e, hipHostMalloc((void**)&e->h_actions_pin, E * 4, hipHostMallocDefault));
+    e->h_obs_dev = (float*)e->h_block_dev; e->h_rew_dev = (double*)(e->h_block_dev + e->h_off_rew);
+    e->h_done_dev = (uint8_t*)(e->h_block_dev + e->h_off_done); e->h_term_dev = (float*)(e->h_block_dev + e->h_off_term);
     return UAVENV_OK;
 }
 
@@ -378,18 +412,29 @@ extern "C" int uavenv_step_host(UavEnv* e, const int32_t* actions, float* obs_ou
                                 float* terminal_obs_out) {
     if (!e || !actions || !obs_out) return UAVENV_E_INVALID;
     int rc = ensure_host_staging(e); if (rc) return rc;
-    size_t E = (size_t)e->num_envs, D = (size_t)e->consts.obs_dim;
+    const size_t E = (size_t)e->num_envs, D = (size_t)e->consts.obs_dim;
     for (size_t i = 0; i < E; i++)
         if (actions[i] < 0 || actions[i] > 4) return fail(e, UAVENV_E_ACTION, "Invalid action: outside 0..4 (uav_env.py:468)");
-    HIP_TRY(e, hipMemcpy(e->h_actions_dev, actions, E * 4, hipMemcpyHostToDevice));
+    // actions through pinned memory, the step, then ONE transfer of [obs | reward | done | status] (and the terminal rows
+    // when asked for) into the pinned mirror: 4096 x 50 = 2.56 MB in ~55 us (tools/pcie_probe.py), then plain memcpys
+    std::memcpy(e->h_actions_pin, actions, E * 4);
+    HIP_TRY(e, hipMemcpyAsync(e->h_actions_dev, e->h_actions_pin, E * 4, hipMemcpyHostToDevice, nullptr));
     rc = uavenv_step(e, e->h_actions_dev, e->h_obs_dev, e->h_rew_dev, nullptr, e->h_done_dev,
                      terminal_obs_out ? e->h_term_dev : nullptr, nullptr);
     if (rc) return rc;
-    HIP_TRY(e, hipMemcpy(obs_out, e->h_obs_dev, E * D * 4, hipMemcpyDeviceToHost));
-    if (reward_out) HIP_TRY(e, hipMemcpy(reward_out, e->h_rew_dev, E * 8, hipMemcpyDeviceToHost));
-    if (done_out) HIP_TRY(e, hipMemcpy(done_out, e->h_done_dev, E, hipMemcpyDeviceToHost));
-    if (terminal_obs_out) HIP_TRY(e, hipMemcpy(terminal_obs_out, e->h_term_dev, E * D * 4, hipMemcpyDeviceToHost));
-    return check_status(e);
+    // the status word rides in the padding behind the done flags (host-validated actions make it zero unless another
+    // entry point flagged something since the last check)
+    HIP_TRY(e, hipMemcpyAsync(e->h_block_dev + e->h_off_term - 16, e->ptrs.status, 4, hipMemcpyDeviceToDevice, nullptr));
+    const size_t bytes = terminal_obs_out ? e->h_block_bytes : e->h_off_term;
+    HIP_TRY(e, hipMemcpyAsync(e->h_block_pin, e->h_block_dev, bytes, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(e, hipStreamSynchronize(nullptr));
+    std::memcpy(obs_out, e->h_block_pin, E * D * 4);
+    if (reward_out) std::memcpy(reward_out, e->h_block_pin + e->h_off_rew, E * 8);
+    if (done_out) std::memcpy(done_out, e->h_block_pin + e->h_off_done, E);
+    if (terminal_obs_out) std::memcpy(terminal_obs_out, e->h_block_pin + e->h_off_term, E * D * 4);
+    uint32_t st;
+    std::memcpy(&st, e->h_block_pin + e->h_off_term - 16, 4);
+    return (st & 1u) ? check_status(e) : UAVENV_OK;
 }
 
 extern "C" int uavenv_time_steps(UavEnv* e, int32_t steps, float* obs, double* rew, uint8_t* done, void* stream,

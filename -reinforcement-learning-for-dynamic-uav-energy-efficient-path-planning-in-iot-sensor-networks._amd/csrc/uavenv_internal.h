@@ -73,6 +73,10 @@ struct Ptrs {
     const float* reset_tape;    // [E][4][G] or nullptr
     uint32_t* status;           // device word: OR of per-env status bits
     unsigned long long* stamps; // diagnostic build only (-DUAVENV_STAMPS): 8 words per wavefront, else unused
+    // optional terminal snapshot (uavenv_enable_terminal_snapshot): what `_get_info()` of the episode's LAST step is made of
+    // (uav_env.py:676-700) -- the record as it stood before the auto-reset, and buffer / generated / transmitted per sensor
+    UavEnvRecord* term_rec;     // [E] or nullptr
+    double* term_sensors;       // [E][3][G] = (data_buffer, total_data_generated, total_data_transmitted) or nullptr
 };
 constexpr uint64_t kOffPosX = 0, kOffPosY = 4, kOffBuffer = 8, kOffGen = 16, kOffTx = 24, kOffLost = 32, kOffAvg = 40,
                    kOffFlags = 48, kSensorBytesPerLane = 52;

@@ -1172,6 +1172,11 @@ __device__ __forceinline__ void step_once(const CT& c, const P& p, const A& a, u
                 st.first_full_coverage_step = r.first_full_coverage_step;
                 st.episode = r.episode; st.valid = 1u;
                 p.stats[env] = st;
+                if (p.term_rec != nullptr) p.term_rec[env] = r;              // the record of the terminal step (before the reset below)
+            }
+            if (p.term_sensors != nullptr && do_reset) {                  // kernel-uniform pointer test
+                double* q = p.term_sensors + ((size_t)env * 3u) * G + gl;
+                q[0] = s.b; q[G] = s.gen; q[2 * G] = s.tx;
             }
         }
         float zD = 0.f, zE = 0.f;

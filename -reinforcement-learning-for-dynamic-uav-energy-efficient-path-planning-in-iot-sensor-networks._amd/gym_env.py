@@ -14,6 +14,7 @@ import torch
 from . import _native as N
 from . import spaces
 from .batched_env import BatchedUAVEnv
+from .info import build_info
 
 try:  # pragma: no cover
     import gymnasium as _gym
@@ -233,29 +234,8 @@ class UAVEnvironment(_Base):
 
     def _get_info(self):
         """uav_env.py:676-700 (17 keys)."""
-        r = self._record()
         s = self._sensors_snapshot()
-        urg = self._get_sensor_urgencies()
-        nvis = int(s["visited"].sum())
-        return {
-            "uav_position": np.array([r["uav_x"], r["uav_y"]], dtype=np.float32),
-            "battery": float(r["battery"]),
-            "battery_percent": float(r["battery"]) / self._cfg.max_battery * 100,
-            "sensors_collected": nvis,
-            "current_step": int(r["current_step"]),
-            "total_reward": float(r["total_reward"]),
-            "total_data_collected": float(r["total_data_collected"]),
-            "coverage_percentage": (nvis / self.num_sensors) * 100,
-            "is_alive": bool(r["battery"] > self._cfg.alive_fraction * self._cfg.max_battery),
-            "max_urgency": float(np.max(urg)),
-            "avg_urgency": float(np.mean(urg)),
-            "high_urgency_sensors": int(np.sum(urg > 0.8)),
-            "capture_effect_triggers": int(r["capture_triggers"]),
-            "boundary_hits": int(r["boundary_hits"]),
-            "edge_steps": int(r["edge_steps"]),
-            "last_step_bytes_collected": float(r["last_step_bytes"]),
-            "sensor_collection_ratios": [float(t / max(g, 1e-6)) for t, g in zip(s["tx"], s["gen"])],
-        }
+        return build_info(self._cfg, self._record(), s["buffer"], s["gen"], s["tx"], int(s["visited"].sum()), self.num_sensors)
 
     def render(self):
         """Visualisation (uav_env.py:706-895) is outside the hot path: no-op."""
@@ -285,6 +265,7 @@ class DomainRandEnv(UAVEnvironment):
         D = self._benv.obs_dim
         self.observation_space = spaces.Box(low=-np.inf, high=np.inf, shape=(D,), dtype=np.float32)   # dqn.py:252-254
         self.last_episode_stats = None
+        self.first_full_coverage_step = None
 
     def set_curriculum_stage(self, stage):
         """dqn.py:258-277: only the grid list sampled at the next reset changes."""
@@ -303,6 +284,7 @@ class DomainRandEnv(UAVEnvironment):
             tg, tc = float(s["gen"].sum()), float(s["tx"].sum())
             used = self._cfg.max_battery - float(r["battery"])
             cov = int(r["first_full_coverage_step"])
+            self.first_full_coverage_step = cov if cov >= 0 else None      # what dqn.py:428-431 tracked for the episode
             self.last_episode_stats = {
                 "total_generated": tg, "total_collected": tc, "total_lost": float(s["lost"].sum()),
                 "battery_remaining": float(r["battery"]),
@@ -312,7 +294,9 @@ class DomainRandEnv(UAVEnvironment):
                 "grid_size": (int(r["grid_w"]), int(r["grid_h"])), "num_sensors": self.num_sensors,
                 "data_efficiency": (tc / tg * 100) if tg > 0 else 0.0,
                 "bytes_per_wh": (tc / used) if used > 0 else 0.0,
-                "time_to_coverage": cov if cov >= 0 else None,
+                # dqn.py:302 sets `_first_full_coverage_step = None` BEFORE the snapshot at :330 reads it, so the reference's
+                # dict always carries None here; the tracked step is kept in `self.first_full_coverage_step`
+                "time_to_coverage": None,
             }
         out = super().reset(**kwargs)
         r = self._record()

@@ -123,7 +123,9 @@ enum {
     UAVENV_F_FLAGS = 7,    /* uint32 [E][stride]  bits 0-3 SF, 4 avg_valid, 5 visited, 6 data_collected */
     UAVENV_F_RECORD = 8,   /* UavEnvRecord [E]                                          */
     UAVENV_F_EPISODE_STATS = 9, /* UavEnvEpisodeStats [E]                              */
-    UAVENV_F_COUNT = 10
+    UAVENV_F_TERM_RECORD = 10,  /* UavEnvRecord [E]: the record of each env's last TERMINAL step (uavenv_enable_terminal_snapshot) */
+    UAVENV_F_TERM_SENSORS = 11, /* double [E][3][stride]: data_buffer, total_data_generated, total_data_transmitted at that step  */
+    UAVENV_F_COUNT = 12
 };
 
 /* noise-tape slots (float [E][slots][stride]); NULL tape = in-kernel Philox4x32-10 */
@@ -241,6 +243,15 @@ int uavenv_set_terminal_pool(UavEnv* env, float* pool_dev, int32_t rows, uint32_
  * [E][4] blocks the buffer holds: uavenv_rollout writes [K][E][4] and refuses K > capacity_steps (UAVENV_E_INVALID)
  * instead of running past the buffer.  NULL disables. */
 int uavenv_set_aux_output(UavEnv* env, float* aux_out_dev, int32_t capacity_steps);
+
+/* Terminal snapshot: what `info` of an episode's LAST step is made of.  With UAVENV_FLAG_AUTO_RESET an environment that
+ * truncates is reset inside the same launch, so the state `_get_info()` (uav_env.py:676-700) describes -- read by
+ * BestByMetricCallback through infos[0] at dqn.py:1150-1155: total_data_collected, battery, sensor_collection_ratios --
+ * is gone when the step returns.  When enabled, the step kernels store, for every environment that ends an episode, its
+ * record as it stood before the reset (UAVENV_F_TERM_RECORD) and data_buffer / total_data_generated /
+ * total_data_transmitted of every sensor (UAVENV_F_TERM_SENSORS); rows of environments that have not ended an episode yet
+ * are zero.  Costs nothing on steps that end no episode.  enable = 0 releases the buffers. */
+int uavenv_enable_terminal_snapshot(UavEnv* env, int32_t enable);
 
 /* ---- frame stack (the caller directly above the path in the trainer: dqn.py:1278) ------------------ */
 /* replaces: SB3 VecFrameStack(n_stack=k).step_wait on device, in place.  stacked_dev float [E][k*obs_dim]

@@ -148,11 +148,31 @@ def test_vec_env_sb3_contract():
             assert dones[k] == tr and abs(rews[k] - rr) <= 1e-5 * max(1, abs(rr))
             if tr:
                 saw_done = True
-                assert np.max(np.abs(infos[k]["terminal_observation"] - oo)) <= 1e-6
-                assert infos[k]["TimeLimit.truncated"] is True
-                assert infos[k]["episode"]["l"] == 20
-                assert abs(infos[k]["episode"]["r"] - ep_ret[k]) <= 1e-9 * max(1, abs(ep_ret[k]))
-                assert infos[k]["last_episode_stats"]["num_sensors"] == 10
+                info = infos[k]
+                assert np.max(np.abs(info["terminal_observation"] - oo)) <= 1e-6
+                assert info["TimeLimit.truncated"] is True
+                assert info["episode"]["l"] == 20
+                assert abs(info["episode"]["r"] - ep_ret[k]) <= 1e-9 * max(1, abs(ep_ret[k]))
+                assert info["last_episode_stats"]["num_sensors"] == 10
+                assert info["last_episode_stats"]["time_to_coverage"] is None          # dqn.py:302 vs :330
+                # the 17 keys of the reference's _get_info() (uav_env.py:676-700) for the TERMINAL step, from the oracle's state
+                # before its reset: what BestByMetricCallback reads through infos[0] (dqn.py:1150-1155)
+                st = envs[k].state()
+                want_ratios = [float(t_ / max(g_, 1e-6)) for t_, g_ in zip(st["tx"], st["gen"])]
+                assert np.allclose(info["sensor_collection_ratios"], want_ratios, rtol=1e-12, atol=0) and len(want_ratios) == 10
+                assert abs(info["total_data_collected"] - float(st["total_collected"])) <= 1e-9
+                assert abs(info["battery"] - float(st["battery"])) <= 1e-9
+                assert abs(info["battery_percent"] - float(st["battery"]) / 274.0 * 100) <= 1e-9
+                assert info["current_step"] == 20 and info["sensors_collected"] == int(st["visited"].sum())
+                assert info["coverage_percentage"] == int(st["visited"].sum()) / 10 * 100
+                assert abs(info["total_reward"] - float(st["total_reward"])) <= 1e-9 * max(1, abs(float(st["total_reward"])))
+                urg = (st["buffer"] / 2.2).astype(np.float32)
+                assert info["max_urgency"] == float(np.max(urg)) and info["avg_urgency"] == float(np.mean(urg))
+                assert info["high_urgency_sensors"] == int(np.sum(urg > 0.8))
+                assert info["capture_effect_triggers"] == int(st["capture_triggers"]) and info["boundary_hits"] == int(st["boundary_hits"])
+                assert info["edge_steps"] == int(st["edge_steps"]) and abs(info["last_step_bytes_collected"] - float(st["last_bytes"])) <= 1e-9
+                assert np.array_equal(info["uav_position"], np.array([st["uav_x"], st["uav_y"]], np.float32)) and info["is_alive"] is True
+                assert len(info) == 17 + 4
                 ep_ret[k] = 0.0
                 oo = envs[k].reset_keyed()
             else:
@@ -172,6 +192,40 @@ def test_vec_env_sb3_contract():
         dr.step(np.zeros(4, dtype=np.int64))
     assert all(g in [(100, 100), (200, 200), (300, 300), (400, 400)] for g in dr.get_attr("grid_size"))
     dr.close()
+
+
+def test_vec_env_per_worker_sensor_counts_and_zero_copy_host_buffers():
+    """dqn.py:1065, :1223-1234: every worker of the reference trainer is pinned to its own sensor count
+    (WORKER_SENSOR_COUNTS = [10, 20, 30, 40]); observations keep 50 slots (zero padded).  Also the host_copies=False mode:
+    views of rotating pinned buffers hold the same numbers as fresh copies."""
+    torch, U, O = _mods()
+    E, counts = 8, [10, 20, 30, 40]
+    kw = dict(domain_rand=True, num_sensors=counts, max_steps=9, seed=12)
+    a = U.UAVVecEnv(E, **kw)
+    b = U.UAVVecEnv(E, host_copies=False, host_buffers=3, **kw)
+    assert a.observation_space.shape == (153,) and a.get_attr("num_sensors") == [counts[i % 4] for i in range(E)]
+    oa, ob = a.reset(), b.reset()
+    assert np.array_equal(oa, ob)
+    for i in range(E):
+        n = counts[i % 4]
+        assert np.all(oa[i, 3 + 3 * n:] == 0.0) and np.any(oa[i, 3:3 + 3 * n] != 0.0)     # ghost slots are zero (dqn.py:286-298)
+    rng = np.random.default_rng(1)
+    kept = []
+    for s in range(30):
+        acts = rng.integers(0, 5, size=E)
+        oa, ra, da, ia = a.step(acts)
+        ob, rb, db, ib = b.step(acts)
+        assert np.array_equal(oa, ob) and np.array_equal(ra, rb) and np.array_equal(da, db)
+        kept.append((s, ob, oa.copy()))
+        for back in (1, 2):                              # a view stays valid for host_buffers - 1 = 2 further steps
+            if len(kept) > back:
+                assert np.array_equal(kept[-1 - back][1], kept[-1 - back][2])
+        for i in np.nonzero(da)[0]:
+            n = counts[i % 4]
+            assert len(ia[i]["sensor_collection_ratios"]) == n == ia[i]["last_episode_stats"]["num_sensors"]
+            assert ia[i]["sensor_collection_ratios"] == ib[i]["sensor_collection_ratios"]
+            assert ia[i]["episode"]["l"] == 9
+    a.close(); b.close()
 
 
 def _sb3_frame_stack_step(stacked, obs, done, term, D):

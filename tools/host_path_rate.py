@@ -20,25 +20,29 @@ env.reset()
 L = N.lib()
 obs = np.zeros((E, env.obs_dim), np.float32); rew = np.zeros(E); done = np.zeros(E, np.uint8)
 acts = np.random.default_rng(0).integers(0, 5, size=(steps, E)).astype(np.int32)
-vp = lambda x: x.ctypes.data_as(C.c_void_p)
+# (plain integer addresses: building ctypes pointer objects per call costs more than the call)
+po, pr, pd, pa, stride = obs.ctypes.data, rew.ctypes.data, done.ctypes.data, acts.ctypes.data, acts.strides[0]
 torch.cuda.synchronize()
 for s in range(20):
-    N.check(L.uavenv_step_host(env._h, vp(acts[s]), vp(obs), vp(rew), vp(done), None), env._h)
+    N.check(L.uavenv_step_host(env._h, pa + s * stride, po, pr, pd, None), env._h)
 t0 = time.perf_counter()
 for s in range(steps):
-    N.check(L.uavenv_step_host(env._h, vp(acts[s]), vp(obs), vp(rew), vp(done), None), env._h)
+    rc = L.uavenv_step_host(env._h, pa + s * stride, po, pr, pd, None)
+    if rc:
+        N.check(rc, env._h)
 dt = time.perf_counter() - t0
 out = {"uavenv_step_host": {"env_steps_per_s": E * steps / dt, "us_per_vector_step": dt / steps * 1e6,
                             "bytes_over_pcie_per_step": E * (4 + env.obs_dim * 4 + 8 + 1)}}
 env.close()
-venv = U.UAVVecEnv(E, num_sensors=n, seed=0)
-venv.reset()
-for s in range(20):
-    venv.step_async(acts[s]); venv.step_wait()
-t0 = time.perf_counter()
-for s in range(steps):
-    venv.step_async(acts[s]); venv.step_wait()
-dt = time.perf_counter() - t0
-out["UAVVecEnv.step"] = {"env_steps_per_s": E * steps / dt, "us_per_vector_step": dt / steps * 1e6}
-venv.close()
+for name, kw in (("UAVVecEnv.step", {}), ("UAVVecEnv.step(host_copies=False)", dict(host_copies=False))):
+    venv = U.UAVVecEnv(E, num_sensors=n, seed=0, **kw)
+    venv.reset()
+    for s in range(20):
+        venv.step_async(acts[s]); venv.step_wait()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        venv.step_async(acts[s]); venv.step_wait()
+    dt = time.perf_counter() - t0
+    out[name] = {"env_steps_per_s": E * steps / dt, "us_per_vector_step": dt / steps * 1e6}
+    venv.close()
 print(json.dumps(out))
