@@ -14,7 +14,8 @@ from .batched_env import BatchedUAVEnv, config_from_kwargs
 from .frame_stack import FrameStack
 from .gym_env import CURRICULUM_STAGES, DomainRandEnv, UAVEnvironment
 from .replay import TransitionRing
+from .learner import DQNLearner, QNetwork, REFERENCE_HYPERPARAMS, td_loss
 from .vec_env import UAVVecEnv
 
-__all__ = ["BatchedUAVEnv", "UAVEnvironment", "DomainRandEnv", "UAVVecEnv", "TransitionRing", "FrameStack", "FusedAttentionFeatures", "pack_attention_weights", "CURRICULUM_STAGES", "UavEnvConfig", "UavEnvError", "default_config", "config_from_kwargs",
+__all__ = ["DQNLearner", "QNetwork", "REFERENCE_HYPERPARAMS", "td_loss", "BatchedUAVEnv", "UAVEnvironment", "DomainRandEnv", "UAVVecEnv", "TransitionRing", "FrameStack", "FusedAttentionFeatures", "pack_attention_weights", "CURRICULUM_STAGES", "UavEnvConfig", "UavEnvError", "default_config", "config_from_kwargs",
            "FLAG_AUTO_RESET", "FLAG_FAR_START", "FLAG_JAIN_BONUS", "FLAG_PROX_SHAPING", "FLAG_RANDOM_LAYOUT"]

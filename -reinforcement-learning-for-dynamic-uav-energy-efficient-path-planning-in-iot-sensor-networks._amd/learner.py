@@ -1,0 +1,266 @@
+"""Device-resident DQN learner over the batched environment (the caller on both sides of the hot path
+in the trainer loop).  It stands where the reference runs
+
+    DQN("MlpPolicy", VecFrameStack(DummyVecEnv([Monitor(DomainRandEnv(..))] * 4), n_stack=4), **HYPERPARAMS).learn(3_000_000)
+
+(agents/dqn/dqn.py:1077-1099 HYPERPARAMS / TRAINING_CONFIG, :1276-1288, :1324) and follows stable-baselines3 2.7's DQN
+semantics -- restated from its public documentation, SB3 is not installed in the build image, so this row is "parity
+unpinned" by a run of SB3 itself; its arithmetic is pinned by tests/test_gpu_learner.py against a hand-written torch
+reference:
+
+  * one rollout = `train_freq` VECTOR steps (each adds num_envs transitions), then `gradient_steps` updates;
+  * `learning_starts`, `exploration_fraction`, the learning-rate schedule and `total_timesteps` count TRANSITIONS
+    (num_timesteps += num_envs per vector step);
+  * the target network is copied every max(target_update_interval // num_envs, 1) vector steps (tau = 1);
+  * loss = smooth-L1(Q(s, a), r + gamma * (1 - done) * max_a' Q_target(s', a')); an episode end by truncation is NOT a
+    `done` for the target (SB3 handle_timeout_termination; `terminated` is always False in this environment,
+    uav_env.py:471), so the target bootstraps from the TERMINAL observation -- which the step kernel has put into the
+    replay ring (replay.py);
+  * Adam, gradient clipping at max_grad_norm = 10;
+  * the learning rate is `schedule(progress_remaining)`; HYPERPARAMS passes `lambda progress: 3e-4 * max(0.1, 1.0 -
+    progress * 0.8)` and SB3 calls it with progress_REMAINING (1 at the start, 0 at the end), so the rate the reference
+    trains with RISES from 6e-5 to 3e-4 (dqn.py:1081's comment says the opposite; the code is what runs);
+  * epsilon-greedy: epsilon falls linearly from 1.0 to `exploration_final_eps` over `exploration_fraction` of the run.
+    SB3's predict() flips ONE coin for the whole vector of environments; with thousands of environments that is an
+    artefact, so every environment flips its own (shared_exploration_coin=True restores SB3's behaviour).
+
+Everything stays on the GPU: the step kernel writes observations and (action, reward, done, terminal ticket) straight
+into the TransitionRing, the frame stack for acting is the uavenv_frame_stack kernel, sampled batches gather their
+frame stacks from the ring (each frame stored once instead of 2 x n_stack times, dqn.py:1085's budget).  With
+torch.distributed initialised, every rank steps its own shard of environments, the ring all-gathers the transition blocks
+(BASELINE config 4) and gradients are averaged, so all ranks hold the same weights.
+"""
+import copy
+import math
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _native as N
+from .frame_stack import FrameStack
+from .replay import TransitionRing
+
+# agents/dqn/dqn.py:1077-1099
+REFERENCE_HYPERPARAMS = dict(
+    learning_rate=lambda progress_remaining: 3e-4 * max(0.1, 1.0 - progress_remaining * 0.8),
+    buffer_size=150_000, batch_size=256, gamma=0.99, learning_starts=25_000, exploration_fraction=0.25,
+    exploration_final_eps=0.03, target_update_interval=5_000, train_freq=4, gradient_steps=1,
+    net_arch=(512, 512, 256), n_stack=4, total_timesteps=3_000_000, max_grad_norm=10.0, exploration_initial_eps=1.0,
+)
+
+
+class AttentionFeatures(nn.Module):
+    """Layer for layer the architecture of the reference's UAVAttentionExtractor (dqn.py:548-650): an MLP over the UAV
+    header of all stacked frames, one-query cross-attention over the 50 sensor slots of the newest frame with ghost
+    and out-of-range slots masked, LayerNorm, fusion to 128 features.  (The module names are this package's; the fused
+    inference kernel accepts both naming schemes, attention.py.)"""
+
+    def __init__(self, n_stack, frame=153, slots=50, embed=64, heads=4, features=128):
+        super().__init__()
+        self.n_stack, self.frame, self.slots = n_stack, frame, slots
+        self.uav = nn.Sequential(nn.Linear(3 * n_stack, embed), nn.LayerNorm(embed), nn.ReLU())
+        self.sensor = nn.Linear(3, embed)
+        self.attn = nn.MultiheadAttention(embed, heads, batch_first=True)
+        self.norm = nn.LayerNorm(embed)
+        self.fuse = nn.Sequential(nn.Linear(2 * embed, features), nn.ReLU())
+        self.features_dim = features
+
+    def forward(self, obs):
+        B = obs.shape[0]
+        fr = obs.view(B, self.n_stack, self.frame)
+        q = self.uav(fr[:, :, :3].reshape(B, -1))
+        sens = fr[:, -1, 3:].view(B, self.slots, 3)
+        mask = (sens.abs().sum(-1) < 1e-6) | (sens[:, :, 2] < 1e-6)
+        mask = mask & ~mask.all(1, keepdim=True)
+        kv = F.relu(self.sensor(sens))
+        ctx, _ = self.attn(q.unsqueeze(1), kv, kv, key_padding_mask=mask)
+        return self.fuse(torch.cat([q, self.norm(ctx.squeeze(1))], -1))
+
+
+class QNetwork(nn.Module):
+    """SB3's DQN "MlpPolicy" q-net: features extractor (Flatten, or the attention extractor) + MLP `net_arch` + 5 outputs."""
+
+    def __init__(self, obs_dim, n_stack, net_arch=(512, 512, 256), extractor="mlp", n_actions=5):
+        super().__init__()
+        if extractor == "attention":
+            self.features = AttentionFeatures(n_stack, frame=obs_dim)
+            d = self.features.features_dim
+        else:
+            self.features = nn.Flatten()
+            d = obs_dim * n_stack
+        layers = []
+        for h in net_arch:
+            layers += [nn.Linear(d, h), nn.ReLU()]
+            d = h
+        self.head = nn.Sequential(*layers, nn.Linear(d, n_actions))
+
+    def forward(self, x):
+        return self.head(self.features(x))
+
+
+def linear_epsilon(progress_remaining, initial, final, fraction):
+    """SB3 get_linear_fn(initial, final, fraction)(progress_remaining)."""
+    done = 1.0 - progress_remaining
+    if done > fraction:
+        return final
+    return initial + done * (final - initial) / fraction
+
+
+def td_loss(q_net, q_target, batch, gamma, reward_scale=1.0):
+    """SB3 DQN.train's loss on one sampled batch: smooth-L1 between Q(s, a) and r + gamma * max_a' Q_target(s', a'),
+    averaged over the transitions whose next observation is available (`valid`).  No (1 - done) factor: every episode
+    end of this environment is a truncation, which SB3 does not treat as terminal for the target."""
+    with torch.no_grad():
+        target = reward_scale * batch["reward"] + gamma * q_target(batch["next_obs"]).max(dim=1).values
+    current = q_net(batch["obs"]).gather(1, batch["action"].unsqueeze(1)).squeeze(1)
+    w = batch["valid"].to(current.dtype)
+    return (F.smooth_l1_loss(current, target, reduction="none") * w).sum() / w.sum().clamp(min=1.0)
+
+
+class DQNLearner:
+    """`DQNLearner(env, **REFERENCE_HYPERPARAMS).learn()` = the reference's `DQN(...).learn(total_timesteps)` on device."""
+
+    def __init__(self, env, learning_rate=REFERENCE_HYPERPARAMS["learning_rate"], buffer_size=150_000, batch_size=256, gamma=0.99,
+                 learning_starts=25_000, exploration_fraction=0.25, exploration_final_eps=0.03, exploration_initial_eps=1.0,
+                 target_update_interval=5_000, train_freq=4, gradient_steps=1, net_arch=(512, 512, 256), n_stack=4,
+                 total_timesteps=3_000_000, max_grad_norm=10.0, extractor="mlp", shared_exploration_coin=False, seed=0,
+                 chunk_len=None, reward_scale=1.0):
+        """reward_scale (not an SB3 / reference option; default 1.0 = theirs): the environment's rewards reach 1e4-1e5 per
+        step (+5000 per new sensor, 100 x bytes x urgency), which a smooth-L1 loss follows at one unit of gradient per
+        sample -- the reference spends 750 k gradient steps on it.  Short runs (the tests) scale the reward in the loss."""
+        self.env, self.dev, self.E, self.D = env, env.device, env.num_envs, env.obs_dim
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.n_envs_total = self.E * self.world                   # SB3's n_envs: transitions per vector step
+        self.lr_schedule = learning_rate if callable(learning_rate) else (lambda _p, v=float(learning_rate): v)
+        self.batch_size, self.gamma, self.learning_starts = int(batch_size), float(gamma), int(learning_starts)
+        self.eps0, self.eps1, self.eps_fraction = float(exploration_initial_eps), float(exploration_final_eps), float(exploration_fraction)
+        self.train_freq, self.gradient_steps = int(train_freq), int(gradient_steps)
+        self.total_timesteps, self.max_grad_norm, self.k = int(total_timesteps), float(max_grad_norm), int(n_stack)
+        self.target_every = max(int(target_update_interval) // self.n_envs_total, 1)     # vector steps (SB3 DQN._on_step)
+        self.shared_coin = bool(shared_exploration_coin)
+        self.reward_scale = float(reward_scale)
+        torch.manual_seed(seed)                                    # same seed on every rank: identical initial weights
+        self.q = QNetwork(self.D, self.k, net_arch, extractor).to(self.dev)
+        self.q_target = copy.deepcopy(self.q).requires_grad_(False)
+        self.opt = torch.optim.Adam(self.q.parameters(), lr=self.lr_schedule(1.0))
+        self.gen = torch.Generator(device=self.dev).manual_seed(seed * 7919 + 13 + self.rank)
+        # replay: buffer_size transitions = buffer_size // n_envs vector slots (SB3 ReplayBuffer), in chunks (one terminal
+        # section and, across ranks, one collective per chunk); one chunk is always being recycled, hence the extra one
+        slots = max(int(buffer_size) // self.n_envs_total, self.k + 2)
+        L = int(chunk_len) if chunk_len else max(1, min(64, slots // 4))
+        capacity = (math.ceil(slots / L) + 1) * L
+        self.ring = TransitionRing(capacity, self.E, self.D, self.dev, world_size=self.world, rank=self.rank, chunk_len=L)
+        self.ring.attach(env)
+        self.fs = FrameStack(self.E, self.D, self.k, self.dev)
+        self.num_timesteps, self.n_calls, self.n_updates = 0, 0, 0
+        self.last_loss = None
+        self._stacked = None
+
+    # ---- schedules ------------------------------------------------------------------------------------
+    def progress_remaining(self):
+        return 1.0 - min(1.0, self.num_timesteps / float(self.total_timesteps))
+
+    def exploration_rate(self):
+        return linear_epsilon(self.progress_remaining(), self.eps0, self.eps1, self.eps_fraction)
+
+    # ---- acting ---------------------------------------------------------------------------------------
+    def _start(self):
+        obs = self.env.reset()
+        self.ring.local_obs_slot().copy_(obs)
+        z = torch.zeros(self.E, device=self.dev)
+        self.ring.commit(z, z, z)                                  # slot 0: the reset observation (no incoming transition)
+        self._stacked = self.fs.reset(obs)
+
+    @torch.no_grad()
+    def act(self, stacked, epsilon):
+        greedy = self.q(stacked).argmax(1).to(torch.int32)
+        if epsilon <= 0.0:
+            return greedy
+        rnd = torch.randint(0, 5, (self.E,), device=self.dev, dtype=torch.int32, generator=self.gen)
+        if self.shared_coin:
+            coin = torch.rand(1, device=self.dev, generator=self.gen).expand(self.E)
+        else:
+            coin = torch.rand(self.E, device=self.dev, generator=self.gen)
+        return torch.where(coin < epsilon, rnd, greedy)
+
+    def collect(self, vector_steps):
+        """SB3 collect_rollouts: `vector_steps` steps of every environment into the replay ring."""
+        if self._stacked is None:
+            self._start()
+        for _ in range(vector_steps):
+            actions = self.act(self._stacked, self.exploration_rate())
+            o, _, d = self.env.step(actions, obs_out=self.ring.local_obs_slot())
+            self.ring.commit()
+            self._stacked = self.fs.step(o, d, None)               # terminal rows live in the ring, not in env.terminal_obs
+            self.num_timesteps += self.n_envs_total
+            self.n_calls += 1
+            if self.n_calls % self.target_every == 0:
+                self.q_target.load_state_dict(self.q.state_dict())
+
+    # ---- learning -------------------------------------------------------------------------------------
+    def train(self, gradient_steps=None):
+        lr = self.lr_schedule(self.progress_remaining())
+        for g in self.opt.param_groups:
+            g["lr"] = lr
+        loss = None
+        for _ in range(self.gradient_steps if gradient_steps is None else gradient_steps):
+            batch = self.ring.sample_stacked(self.batch_size, self.k, generator=self.gen)
+            loss = td_loss(self.q, self.q_target, batch, self.gamma, self.reward_scale)
+            self.opt.zero_grad(set_to_none=True)
+            loss.backward()
+            if self.world > 1:                                     # replicas stay identical: average the gradients
+                for p in self.q.parameters():
+                    dist.all_reduce(p.grad)
+                    p.grad.div_(self.world)
+            nn.utils.clip_grad_norm_(self.q.parameters(), self.max_grad_norm)
+            self.opt.step()
+            self.n_updates += 1
+        self.last_loss = loss
+        return loss
+
+    def learn(self, total_timesteps=None, callback=None):
+        """SB3 OffPolicyAlgorithm.learn: rollouts of `train_freq` vector steps, each followed -- once `learning_starts`
+        transitions have been collected -- by `gradient_steps` updates."""
+        if total_timesteps is not None:
+            self.total_timesteps = int(total_timesteps)
+        while self.num_timesteps < self.total_timesteps:
+            self.collect(self.train_freq)
+            if self.num_timesteps > self.learning_starts and self.ring.sampleable() >= self.k + 2:
+                self.train()
+            if callback is not None and callback(self) is False:
+                break
+        return self
+
+    # ---- evaluation -----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def evaluate(self, eval_env, episodes_per_env=1, policy="greedy"):
+        """Mean return (sum of the rewards the step returns) over the first `episodes_per_env` complete episodes of every
+        environment of `eval_env`; policy "greedy" (argmax Q, SB3 predict(deterministic=True)) or "random"."""
+        E, D = eval_env.num_envs, eval_env.obs_dim
+        fs = FrameStack(E, D, self.k, self.dev)
+        stacked = fs.reset(eval_env.reset())
+        done_count = torch.zeros(E, device=self.dev)
+        returns = []
+        cur = torch.zeros(E, dtype=torch.float64, device=self.dev)
+        gen = torch.Generator(device=self.dev).manual_seed(12345)
+        guard = 0
+        while bool((done_count < episodes_per_env).any()) and guard < 100000:
+            guard += 1
+            if policy == "greedy":
+                a = self.q(stacked).argmax(1).to(torch.int32)
+            else:
+                a = torch.randint(0, 5, (E,), device=self.dev, dtype=torch.int32, generator=gen)
+            o, r, d = eval_env.step(a)
+            cur += r
+            db = d.bool()
+            take = db & (done_count < episodes_per_env)
+            if bool(take.any()):
+                returns.append(cur[take].clone())
+            done_count += db
+            cur = torch.where(db, torch.zeros_like(cur), cur)
+            stacked = fs.step(o, d, eval_env.terminal_obs)
+        allr = torch.cat(returns)
+        return float(allr.mean()), int(allr.numel())
