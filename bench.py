@@ -145,6 +145,7 @@ def main():
     distributed = world > 1 or selftest
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import uavenv_amd as U
@@ -307,7 +308,7 @@ def main():
         fused = {"steps_per_launch": F, "launches": launches, "ms_per_launch": fms,
                  "env_steps_per_s": E * F / (fms * 1e-3),
                  "achieved_GBps": algorithmic_bytes_per_env_step(n) * E * F / (fms * 1e-3) / 1e9,
-                 "kernel": "uav_rollout_kernel<64, true>"}
+                 "kernel": "uav_rollout_kernel<64, true, true>"}
 
     total_env_steps = E * K * world
     value = total_env_steps / dt
@@ -341,7 +342,8 @@ def main():
                                                                 "this_run_commit": build_commit()},
                      "achieved_from_traffic": None if not (tr or {}).get("hbm_bytes_per_launch") else
                      tr["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9,
-                     "kernel": "uav_step_kernel<64, true>", "algorithmic_bytes_per_launch": per_launch_bytes,
+                     "kernel": "uav_step_kernel<64, true, 16, true> (lane group 64, lean, 16-wave workgroups, default-config literals)",
+                     "algorithmic_bytes_per_launch": per_launch_bytes,
                      "algorithmic_bytes_per_env_step": B, "avg_launch_ms": kern_ms,
                      "timed_region_event_ms_per_step": ev_ms / K,
                      "note": "path is VALU/latency bound (Philox + float64 physics per sensor), not HBM bound: "
