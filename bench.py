@@ -113,6 +113,23 @@ def latest_valu_per_wave():
     return best
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when its first communicator comes up; the contract is ONE JSON line there.
+    Everything written to file descriptor 1 inside this block goes to stderr instead."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,7 +163,11 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            warm = torch.zeros(1, device=dev)
+            dist.all_reduce(warm)                  # brings the communicator (and its banner) up now
+            torch.cuda.synchronize(dev)
 
     import uavenv_amd as U
     from uavenv_amd.replay import TransitionRing
