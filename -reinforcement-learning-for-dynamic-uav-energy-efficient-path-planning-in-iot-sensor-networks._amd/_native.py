@@ -90,9 +90,16 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        from . import build as _b
-        _b.build()
+    from . import build as _b
+    try:
+        _b.hipcc()
+        have_compiler = True
+    except RuntimeError:
+        have_compiler = False
+    if have_compiler:
+        _b.build()          # no-op unless a source / header is newer than the library (a stale binary would load silently)
+    elif not os.path.exists(LIB_PATH):
+        raise UavEnvError("libuavenv_hip.so is missing and hipcc is not available to build it")
     L = C.CDLL(LIB_PATH)   # raises OSError loudly if missing / unloadable: no fallback path exists
     vp, i32, u32, u64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64
     cfgp = C.POINTER(UavEnvConfig)
