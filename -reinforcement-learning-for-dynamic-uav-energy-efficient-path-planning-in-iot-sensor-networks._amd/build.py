@@ -27,12 +27,24 @@ def hipcc():
     raise RuntimeError("hipcc not found: the uavenv HIP extension cannot be built")
 
 
+STAMP = LIB + ".srchash"
+
+
+def source_hash():
+    """Hash of everything the library is built from (content, not mtimes: a snapshot copied to the GPU box gets new ones)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for d in [os.path.join(CSRC, s) for s in SOURCES + HEADERS]:
+        if os.path.basename(d) == "uavenv_default_consts.inc":
+            continue                      # generated from the other inputs
+        h.update(open(d, "rb").read())
+    return h.hexdigest()
+
+
 def stale():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return open(STAMP).read().strip() != source_hash()
 
 
 def generate_default_consts(verbose=False):
@@ -60,6 +72,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(source_hash() + "\n")
     return LIB
 
 
