@@ -79,6 +79,7 @@ class TransitionRing:
         self.size = 0                 # number of sampleable slots behind the head
         self._pending = [None] * self.n_chunks     # outstanding collective per chunk
         self._comm_stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+        self._used_comm = False
 
     # ---- the terminal section of a chunk ---------------------------------------------------------------
     def local_terminal_section(self, chunk=None):
@@ -141,6 +142,7 @@ class TransitionRing:
         """One in-place all-gather of this rank's part of chunk c (RCCL on a side stream / gloo on CPU)."""
         out, inp = self.store[c].view(-1), self.store[c, self.rank].view(-1)
         if self._comm_stream is not None:
+            self._used_comm = True
             self._comm_stream.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self._comm_stream):
                 w = dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
@@ -228,8 +230,8 @@ class TransitionRing:
     def drain(self):
         for c in range(self.n_chunks):
             self.wait_chunk(c)
-        if self._comm_stream is not None:
-            torch.cuda.current_stream(self.device).wait_stream(self._comm_stream)
+        if self._comm_stream is not None and self._used_comm:        # (a cross-stream wait costs several us of GPU time even
+            torch.cuda.current_stream(self.device).wait_stream(self._comm_stream)   # when the side stream never ran anything)
 
     # ---- consumer side -----------------------------------------------------------------------
     def sampleable(self):

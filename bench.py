@@ -251,25 +251,30 @@ def main():
     run_steps(W, align=True)
     ring.drain()
 
-    def timed_region():
-        """EXACTLY K steps between two barrier + synchronize brackets; returns (wall s, enqueue s, device-event ms)."""
+    def timed_region(with_events=False):
+        """EXACTLY K steps between two barrier + synchronize brackets; returns (wall s, enqueue s, device-event ms or None).
+        The regions that produce `value` record NO events: an event pair costs ~10 us of completion latency on an idle
+        GPU (tools/bracket_probe.py: 22 us around an empty region with events, 3 us without), which is noise of the order
+        of a step in a short region.  The device-event figure comes from one extra region that is not counted."""
         barrier()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0 = ev1 = None
+        if with_events:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        ev0.record()                       # torch's current stream IS the stream the kernel is launched on
+        if with_events:
+            ev0.record()                   # torch's current stream IS the stream the kernel is launched on
         run_steps(K)
         t_enq = time.perf_counter() - t0
-        ev1.record()
+        if with_events:
+            ev1.record()
         ring.drain()
-        while not ev1.query():             # poll instead of sleeping in the driver: the wake-up latency of a blocking
-            pass                           # wait (10-20 us) is host noise of the order of a step
         barrier()
         dt_ = time.perf_counter() - t0
         if distributed:
             t = torch.tensor([dt_], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt_ = float(t.item())
-        return dt_, t_enq, ev0.elapsed_time(ev1)
+        return dt_, t_enq, (ev0.elapsed_time(ev1) if with_events else None)
 
     # A region of a few dozen steps lasts a fraction of a millisecond, where one scheduling hiccup of the host moves the
     # figure by 10 %: short regions are REPEATED (each one exactly K steps in its own brackets, re-aligned to a chunk
@@ -280,7 +285,9 @@ def main():
         regions.append(timed_region())
         run_steps(0, align=True)
     regions.sort(key=lambda x: x[0])
-    dt, t_enq, ev_ms = regions[len(regions) // 2]
+    dt, t_enq, _ = regions[len(regions) // 2]
+    ev_ms = timed_region(with_events=True)[2]          # diagnostic only
+    run_steps(0, align=True)
 
     # Kernel-only launch duration, HIP events on the launch stream around back-to-back launches
     # (measured on every rank, after the timed region so it cannot perturb it)
