@@ -13,9 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _module(n_stack):
-    sys.path.insert(0, os.path.join(ROOT, "examples"))
     import torch
-    from train_dqn import AttentionFeatures
+    from uavenv_amd.learner import AttentionFeatures
     torch.manual_seed(0)
     m = AttentionFeatures(n_stack).cuda().eval()
     with torch.no_grad():                       # non-trivial LayerNorm / bias parameters

@@ -114,6 +114,9 @@ for E, n in ((37, 50), (256, 50), (100, 20), (64, 10), (4096 + 37, 50), (8192 + 
             a = torch.randint(0, 5, (E,), generator=g, dtype=torch.int32).to(env.device)
             env.step(a)
         h.update(env.obs.cpu().numpy().tobytes()); h.update(env.reward.cpu().numpy().tobytes()); h.update(env.done.cpu().numpy().tobytes())
+    ro = env.rollout(6)                                  # the fused kernel too
+    for k in ("obs", "reward", "done", "actions"):
+        h.update(ro[k].cpu().numpy().tobytes())
     sd = env.state_dict()
     for k in sorted(sd):
         h.update(sd[k].cpu().numpy().tobytes())
@@ -132,6 +135,20 @@ def test_simd_load_balancing_is_a_pure_scheduling_choice():
                                       env=dict(os.environ, UAVENV_NO_BALANCE=flag))
         outs.append([l for l in out.splitlines() if l.startswith("DIGEST")][0])
     assert outs[0] == outs[1]
+
+
+def test_literal_constants_and_write_through_stores_change_no_bit():
+    """Round-2 code-generation choices: the default configuration's constants as instruction literals (kDefC, chosen when the
+    handle's constants block is bit-identical to the defaults) and `sc1` write-through stores (batches of >= 4096 wavefronts).
+    Same digest -- observations, rewards, done flags, fused rollouts, final state -- with either switched off."""
+    import sys
+    digests = {}
+    for lit in ("0", "1"):
+        for wt in ("0", "1"):
+            out = subprocess.check_output([sys.executable, "-c", _BALANCE_CHILD % ROOT], text=True,
+                                          env=dict(os.environ, UAVENV_NO_LITERALS=lit, UAVENV_WRITE_THROUGH=wt))
+            digests[(lit, wt)] = [l for l in out.splitlines() if l.startswith("DIGEST")][0]
+    assert len(set(digests.values())) == 1, digests
 
 
 def test_action_words_never_outlive_the_seed_or_the_state():

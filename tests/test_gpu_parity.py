@@ -149,6 +149,14 @@ KEYED_CASES = [
     ("n50_big_workgroups", 4096 + 21, dict(num_sensors=50, max_steps=9, duty_cycle=60.0, grid_size=(150, 150)), 14, 0),
     ("n20_big_workgroups", 8192 + 5, dict(num_sensors=20, max_steps=7, duty_cycle=80.0, grid_size=(120, 120)), 10, 0),
     ("n10_big_workgroups", 16384 + 3, dict(num_sensors=10, max_steps=6, duty_cycle=100.0, grid_size=(90, 90)), 8, 0),
+    # the DEFAULT constants (only the step limit and the sizes differ: the literal-constant kernels run), small and chip-filling
+    # batches (write-through stores), every lane-group width
+    ("n50_default_consts", 200, dict(num_sensors=50, max_steps=40), 90, 0),
+    ("n20_default_consts", 300, dict(num_sensors=20, max_steps=40), 90, 0),
+    ("n10_default_consts", 500, dict(num_sensors=10, max_steps=40), 90, 0),
+    ("n50_default_consts_big", 4096 + 21, dict(num_sensors=50, max_steps=9), 14, 0),
+    ("n20_default_consts_big", 8192 + 5, dict(num_sensors=20, max_steps=7), 10, 0),
+    ("n10_default_consts_big", 16384 + 3, dict(num_sensors=10, max_steps=6), 8, 0),
 ]
 
 
