@@ -90,6 +90,9 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    override = os.environ.get("UAVENV_LIB")          # dev tools (tools/exp.sh): load an experimental build of the library
+    if override:
+        return _load(override)
     from . import build as _b
     try:
         _b.hipcc()
@@ -100,7 +103,12 @@ def lib():
         _b.build()          # no-op unless a source / header is newer than the library (a stale binary would load silently)
     elif not os.path.exists(LIB_PATH):
         raise UavEnvError("libuavenv_hip.so is missing and hipcc is not available to build it")
-    L = C.CDLL(LIB_PATH)   # raises OSError loudly if missing / unloadable: no fallback path exists
+    return _load(LIB_PATH)
+
+
+def _load(path):
+    global _lib
+    L = C.CDLL(path)       # raises OSError loudly if missing / unloadable: no fallback path exists
     vp, i32, u32, u64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64
     cfgp = C.POINTER(UavEnvConfig)
     sig = {

@@ -17,4 +17,4 @@ for v in "$@"; do
 done
 wait
 grep -l "error" tools/_exp/build_*.log 2>/dev/null && { grep -h "error" tools/_exp/build_*.log | head; exit 1; }
-tools/gpu.sh --timeout 600 "python3 tools/exp_time.py $names"
+tools/gpu.sh --timeout 600 "${EXP_CMD:-python3 tools/exp_time.py} $names"
