@@ -98,18 +98,24 @@ def build_commit():
     return open(p).read().strip() if os.path.exists(p) else None
 
 
-def latest_valu_per_wave():
-    """VALU instructions per wavefront of the step kernel from the committed SQ-counter summary
-    (profiles/*sq_counters*.txt, tools/pmc_rollout.sh), or None."""
+def latest_sq_counters(envs):
+    """Per-wave SQ counters of the step kernel at `envs` environments from the committed summary
+    (profiles/*sq_counters*.txt, tools/pmc_sq.sh: separate rocprofv3 --pmc passes), or None."""
     best = None
     for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*sq_counters*.txt"))):
+        cur = {}
         try:
             for line in open(p):
                 f = line.split()
-                if len(f) >= 5 and f[0] == "step" and f[1] == "SQ_INSTS_VALU":
-                    best = float(f[4])
+                if len(f) >= 6 and f[0] == "step" and f[1].startswith("envs=") and f[3].startswith("SQ_") and f[4] == "per":
+                    if int(f[2]) == envs:
+                        cur[f[3]] = float(f[6])
+                elif len(f) >= 6 and f[0] == "step" and f[1] == "envs=" + str(envs) and f[2].startswith("SQ_"):
+                    cur[f[2]] = float(f[5])
         except Exception:
-            pass
+            cur = {}
+        if cur:
+            best = dict(cur, file=os.path.relpath(p, ROOT))
     return best
 
 
@@ -128,6 +134,17 @@ class stdout_to_stderr:
         os.dup2(self._saved, 1)
         os.close(self._saved)
         return False
+
+
+def issue_split(E, n):
+    sq = latest_sq_counters(E) if n == 50 else None
+    if not sq or "SQ_WAVE_CYCLES" not in sq:
+        return None
+    wc = sq["SQ_WAVE_CYCLES"]
+    return {"valu_insts_per_wave": sq.get("SQ_INSTS_VALU"), "scalar_insts_per_wave": sq.get("SQ_INSTS_SALU"),
+            "wave_cycles": 4 * wc, "frac_issuing": sq.get("SQ_ACTIVE_INST_ANY", 0) / wc,
+            "frac_parked_in_waitcnt": sq.get("SQ_WAIT_ANY", 0) / wc, "frac_issue_stalled": sq.get("SQ_WAIT_INST_ANY", 0) / wc,
+            "frac_valu_active": sq.get("SQ_ACTIVE_INST_VALU", 0) / wc, "source": sq["file"]}
 
 
 def main():
@@ -156,6 +173,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
+    # Rehearsal switch (never the driver's configuration): UAVENV_BENCH_REHEARSE=gloo runs the N > 1 path with every rank on
+    # cuda:0 and the gloo backend -- a one-GPU box can then exercise the sharded launch, the ring exchange and the max-over-
+    # ranks timing end to end (RCCL itself needs one GPU per rank).
+    rehearse = os.environ.get("UAVENV_BENCH_REHEARSE") == "gloo"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     selftest = os.environ.get("UAVENV_BENCH_SELFTEST_DIST") == "1"     # dev: run the N>1 code path on one rank
@@ -164,7 +187,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         with stdout_to_stderr():
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            if rehearse:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
             warm = torch.zeros(1, device=dev)
             dist.all_reduce(warm)                  # brings the communicator (and its banner) up now
             torch.cuda.synchronize(dev)
@@ -357,7 +383,7 @@ def main():
                    "envs_per_gpu": E, "sensors": n, "grid": args.grid, "obs_dim": env.obs_dim,
                    "exchange": (f"one in-place rccl all_gather per {L} steps of every rank's {L} transition blocks into a shared replay ring"
                                 if exchange == "allgather" else "none (observations written in place into the replay ring)"),
-                   "parallelism": f"env-shard x{world}",
+                   "parallelism": f"env-shard x{world}" + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearse else ""),
                    "launch": (f"one step per kernel launch; launches replayed as HIP graphs of {L} steps (one ring chunk)"
                               if graphs is not None else "one step per kernel launch, launched from Python"),
                    "host_enqueue_us_per_step": t_enq / K * 1e6,
@@ -376,12 +402,9 @@ def main():
                      "timed_region_event_ms_per_step": ev_ms / K,
                      "note": "path is VALU/latency bound (Philox + float64 physics per sensor), not HBM bound: "
                              "see DESIGN.md"},
-        # what the launch is actually bound by, for context (not a roofline the contract asks for): share of the chip's
-        # VALU issue slots the launch uses = instructions per wave (committed SQ counters, 4 cycles each on a SIMD) x waves
-        # / (1024 SIMDs x 2.4 GHz x launch duration)
-        "valu_issue": (None if latest_valu_per_wave() is None or n != 50 or E != 4096 else
-                       {"valu_insts_per_wave": latest_valu_per_wave(),
-                        "frac_of_issue_slots": latest_valu_per_wave() * 4.0 * (E * 64 // 64) / (1024 * 2.4e9 * kern_ms * 1e-3)}),
+        # what the launch is actually bound by, for context (not a roofline the contract asks for): the measured split of a wave's
+        # life into issuing / parked in s_waitcnt / issue stalls (SQ counters, quad-cycles; separate profiler passes)
+        "issue_split": issue_split(E, n),
     }
     if fused:
         out["fused_rollout"] = fused
