@@ -74,7 +74,7 @@ EXPORTS = [
     "uavenv_abi_version", "uavenv_default_config", "uavenv_obs_dim", "uavenv_create", "uavenv_destroy",
     "uavenv_last_error", "uavenv_num_envs", "uavenv_lane_stride", "uavenv_env_obs_dim", "uavenv_set_env_params",
     "uavenv_set_positions", "uavenv_set_seed", "uavenv_set_grid_choices", "uavenv_set_noise_tape",
-    "uavenv_dump_noise", "uavenv_reset", "uavenv_step", "uavenv_step_random", "uavenv_step_policy", "uavenv_rollout", "uavenv_frame_stack", "uavenv_set_terminal_pool", "uavenv_set_aux_output", "uavenv_enable_terminal_snapshot", "uavenv_attention_weight_floats", "uavenv_attention_features", "uavenv_get_state",
+    "uavenv_dump_noise", "uavenv_reset", "uavenv_step", "uavenv_step_random", "uavenv_step_random_n", "uavenv_step_policy", "uavenv_rollout", "uavenv_frame_stack", "uavenv_set_terminal_pool", "uavenv_set_aux_output", "uavenv_enable_terminal_snapshot", "uavenv_attention_weight_floats", "uavenv_attention_features", "uavenv_get_state",
     "uavenv_set_state", "uavenv_state_bytes", "uavenv_reset_host", "uavenv_step_host", "uavenv_time_steps",
 ]
 
@@ -130,6 +130,7 @@ def _load(path):
         "uavenv_reset": (C.c_int, [vp, vp, vp, vp]),
         "uavenv_step": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
         "uavenv_step_random": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
+        "uavenv_step_random_n": (C.c_int, [vp, i32, vp, C.c_int64, vp, C.c_int64, vp, vp, vp]),
         "uavenv_step_policy": (C.c_int, [vp, i32, vp, vp, vp, vp, vp, vp, vp]),
         "uavenv_rollout": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
         "uavenv_set_terminal_pool": (C.c_int, [vp, vp, i32, vp, vp]),

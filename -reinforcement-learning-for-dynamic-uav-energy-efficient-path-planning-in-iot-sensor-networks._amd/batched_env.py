@@ -241,6 +241,19 @@ class BatchedUAVEnv:
             N.check(rc, self._h)
         return obs, self.reward, self.done
 
+    def step_random_n(self, num_steps, obs_first, obs_stride, aux_first=None, aux_stride=0):
+        """`num_steps` random-policy steps issued by ONE call into the C library (uavenv_step_random_n): step k writes its
+        observations at obs_first + k * obs_stride floats (and its aux block at aux_first + k * aux_stride), e.g. the slots of a
+        replay-ring chunk.  Same results as calling step_random() num_steps times; `self.reward32` / `self.done` hold the last
+        step's values."""
+        assert obs_first.is_cuda and obs_first.dtype == torch.float32
+        rc = self.L.uavenv_step_random_n(self._h, int(num_steps), obs_first.data_ptr(), int(obs_stride),
+                                         0 if aux_first is None else aux_first.data_ptr(), int(aux_stride),
+                                         self.reward32.data_ptr(), self.done.data_ptr(),
+                                         torch.cuda.current_stream(self.device).cuda_stream)
+        if rc:
+            N.check(rc, self._h)
+
     def step_policy(self, policy, obs_out=None):
         """Step with the action chosen in the kernel: N.POLICY_RANDOM, N.POLICY_NEAREST (NearestSensorGreedy) or
         N.POLICY_MAX_THROUGHPUT_V2 (greedy_agents.py); the actions land in `self.actions_taken`."""

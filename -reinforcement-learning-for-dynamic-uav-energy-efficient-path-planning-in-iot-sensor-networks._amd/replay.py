@@ -218,6 +218,18 @@ class TransitionRing:
         self._point_env()          # capturing executed nothing
         return graphs
 
+    def run_chunk_random(self):
+        """The chunk at the head stepped with the in-kernel random policy: L single-step launches issued by ONE call into the
+        C library (BatchedUAVEnv.step_random_n) -- no graph to capture, and the first kernel starts after one packet."""
+        assert self._env is not None and self.head % self.L == 0
+        c = self.head // self.L
+        self.wait_chunk(c)
+        self._count[c, self.rank].zero_()
+        self._point_env(c * self.L)                     # terminal section of this chunk
+        self._env.step_random_n(self.L, self._obs5[c, self.rank, 0], self.block, self._aux5[c, self.rank, 0], self.block)
+        self._advance(self.L, zero_counts=False)
+        self._point_env()
+
     def replay_chunk(self, graphs):
         """Replay the graph of the chunk at the head and commit its L slots."""
         c = self.head // self.L

@@ -158,7 +158,10 @@ def main():
     ap.add_argument("--exchange", choices=["auto", "none", "allgather"], default="auto")
     ap.add_argument("--ring", type=int, default=128, help="replay-ring slots used by the bench (two chunks = two HIP graphs / collectives)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of replaying HIP graphs")
+    ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of chunk by chunk")
+    ap.add_argument("--launch", choices=["batch", "graph"], default="graph",
+                    help="how a ring chunk of L steps is issued: 'batch' = L single-step launches from one call into the C "
+                         "library (uavenv_step_random_n), 'graph' = one HIP-graph replay of the captured L launches")
     ap.add_argument("--repeats", type=int, default=0, help="timed regions of K steps each (median reported); 0 = as many as ~1500 steps need, at most 15")
     ap.add_argument("--fused", type=int, default=16, help="steps per launch of the additional fused-rollout measurement (0 = skip)")
     args = ap.parse_args()
@@ -260,18 +263,26 @@ def main():
     # ranks that share the ring all-gather a chunk (one in-place RCCL collective of L transition blocks per rank, side
     # stream, overlapping the next chunk's steps) when it is complete.  Steps that do not fill a chunk launch eagerly.
     graphs = None
+    chunked = use_graph
     if use_graph:
         while ring.head % L:
             one_step()
-        graphs = ring.capture_chunks(lambda slot: env.step_random(obs_out=slot))
+        if args.launch == "graph":
+            graphs = ring.capture_chunks(lambda slot: env.step_random(obs_out=slot))
+
+    def run_chunk():
+        if graphs is not None:
+            ring.replay_chunk(graphs)
+        else:
+            ring.run_chunk_random()
 
     def run_steps(n, align=False):
-        q, r = divmod(n, L) if graphs is not None else (0, n)
+        q, r = divmod(n, L) if chunked else (0, n)
         for _ in range(q):
-            ring.replay_chunk(graphs)
+            run_chunk()
         for _ in range(r):
             one_step()
-        while align and graphs is not None and ring.head % L:      # untimed: back to a chunk boundary
+        while align and chunked and ring.head % L:      # untimed: back to a chunk boundary
             one_step()
 
     run_steps(W, align=True)
@@ -327,7 +338,7 @@ def main():
     if exchange == "allgather":
         ring.drain()
         ring = make_ring(False)
-        graphs = ring.capture_chunks(lambda slot: env.step_random(obs_out=slot)) if use_graph else None
+        graphs = ring.capture_chunks(lambda slot: env.step_random(obs_out=slot)) if (use_graph and args.launch == "graph") else None
         run_steps(W, align=True)
         barrier()
         t1 = time.perf_counter()
@@ -384,8 +395,9 @@ def main():
                    "exchange": (f"one in-place rccl all_gather per {L} steps of every rank's {L} transition blocks into a shared replay ring"
                                 if exchange == "allgather" else "none (observations written in place into the replay ring)"),
                    "parallelism": f"env-shard x{world}" + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearse else ""),
-                   "launch": (f"one step per kernel launch; launches replayed as HIP graphs of {L} steps (one ring chunk)"
-                              if graphs is not None else "one step per kernel launch, launched from Python"),
+                   "launch": (f"one step per kernel launch; launches replayed as HIP graphs of {L} steps (one ring chunk)" if graphs is not None
+                              else f"one step per kernel launch; the {L} launches of a ring chunk issued by one call into the C library "
+                                   f"(uavenv_step_random_n)" if chunked else "one step per kernel launch, launched from Python"),
                    "host_enqueue_us_per_step": t_enq / K * 1e6,
                    "arithmetic": "float64 state and rewards, float32 distance chain and observations (the reference's own mix)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

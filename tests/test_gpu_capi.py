@@ -137,6 +137,45 @@ def test_simd_load_balancing_is_a_pure_scheduling_choice():
     assert outs[0] == outs[1]
 
 
+def test_ring_chunk_from_one_c_call_equals_the_eager_loop():
+    """uavenv_step_random_n / TransitionRing.run_chunk_random: the L launches of a chunk issued by one call into the library
+    leave the same ring contents, terminal rows and environment state as L step_random() + commit() calls."""
+    import torch
+    import uavenv_amd as U
+    from uavenv_amd.replay import TransitionRing
+    kw = dict(num_sensors=50, seed=9, max_steps=13)
+    E, L = 200, 8
+    envs, rings = [], []
+    for _ in range(2):
+        e = U.BatchedUAVEnv(E, **kw)
+        r = TransitionRing(3 * L, E, e.obs_dim, e.device, chunk_len=L)
+        r.attach(e); e.reset()
+        envs.append(e); rings.append(r)
+    (ea, eb), (ra, rb) = envs, rings
+    all_e = torch.arange(E, device=ea.device)
+    n_term = 0
+    for rev in range(5):
+        for _ in range(L):
+            ea.step_random(obs_out=ra.local_obs_slot()); ra.commit()
+        rb.run_chunk_random()
+        torch.cuda.synchronize()
+        assert ra.head == rb.head and ra.size == rb.size
+        c0 = ((rb.head - L) % rb.capacity)
+        for slot in range(c0, c0 + L):
+            aa, ab = ra.aux_at(slot, 0, all_e), rb.aux_at(slot, 0, all_e)
+            assert torch.equal(ra.obs_at(slot, 0, all_e), rb.obs_at(slot, 0, all_e)) and torch.equal(aa[:, :3], ab[:, :3])
+            ta, tb = ra.tickets_at(slot, 0, all_e).long(), rb.tickets_at(slot, 0, all_e).long()
+            assert torch.equal(ta >= 0, tb >= 0)
+            m = ta >= 0
+            if bool(m.any()):
+                assert torch.equal(ra.terminal_at(slot, 0, ta[m]), rb.terminal_at(slot, 0, tb[m])); n_term += int(m.sum())
+        assert torch.equal(ea.reward32, eb.reward32) and torch.equal(ea.done, eb.done)
+    assert n_term >= 2 * E
+    sa, sb = ea.state_dict(), eb.state_dict()
+    assert all(torch.equal(sa[k], sb[k]) for k in sa)
+    ea.close(); eb.close()
+
+
 def test_literal_constants_and_write_through_stores_change_no_bit():
     """Round-2 code-generation choices: the default configuration's constants as instruction literals (kDefC, chosen when the
     handle's constants block is bit-identical to the defaults) and `sc1` write-through stores (batches of >= 4096 wavefronts).
