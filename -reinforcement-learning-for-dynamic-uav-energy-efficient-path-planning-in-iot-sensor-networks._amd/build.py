@@ -17,7 +17,7 @@ GENERATED = os.path.join(CSRC, "uavenv_default_consts.inc")
 # -ffp-contract=off: the float64 state has to follow the reference's (numpy, unfused) operation order.
 # kernarg preload: the leading scalar kernel arguments arrive in SGPRs with the wave launch (see uav_step_kernel).
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall", "-Wno-bitwise-instead-of-logical",
-         "-mllvm", "-amdgpu-kernarg-preload-count=7"]
+         "-mllvm", "-amdgpu-kernarg-preload-count=8"]
 
 
 def hipcc():

@@ -261,13 +261,15 @@ static int step_common(UavEnv* e, int32_t policy, const int32_t* actions, int32_
     if (!e) return UAVENV_E_INVALID;
     if (policy < UAVENV_POLICY_ACTIONS || policy > UAVENV_POLICY_MAX_THROUGHPUT_V2) return fail(e, UAVENV_E_INVALID, "unknown policy");
     if (policy == UAVENV_POLICY_ACTIONS && !actions) return fail(e, UAVENV_E_INVALID, "actions_dev is NULL");
-    StepArgs a{actions, actions_out, obs, rew, rew32, done, term, e->num_envs,
-               e->term_pool, e->term_counter, e->term_index, e->term_rows, policy, aux_override ? aux_override : e->aux_out, nullptr, nullptr, 0,
-               e->write_through ? 1 : 0};
+    StepArgs a{};
+    a.actions = actions; a.num_envs = e->num_envs; a.policy = policy;
+    a.out.actions_out = actions_out; a.out.obs = obs; a.out.reward = rew; a.out.reward32 = rew32; a.out.done = done; a.out.term_obs = term;
+    a.out.term_pool = e->term_pool; a.out.term_counter = e->term_counter; a.out.term_index = e->term_index; a.out.term_rows = e->term_rows;
+    a.out.aux = aux_override ? aux_override : e->aux_out; a.out.write_through = e->write_through ? 1 : 0;
     a.hint_in = e->hints + (size_t)e->hint_parity * (size_t)e->padded_envs;          // always a readable buffer
     a.balance = e->balance ? 1 : 0;
     if (policy == UAVENV_POLICY_RANDOM) {                         // this launch leaves the next launch's action words
-        a.hint_out = e->hints + (size_t)(e->hint_parity ^ 1) * (size_t)e->padded_envs;
+        a.out.hint_out = e->hints + (size_t)(e->hint_parity ^ 1) * (size_t)e->padded_envs;
         e->hint_parity ^= 1;
     } else if (policy != UAVENV_POLICY_ACTIONS) a.balance = 0;   // no cheap way to know the actions up front
     HIP_TRY(e, launch_step(e->G, e->padded_envs, e->consts, e->dev_consts, e->ptrs, a, e->default_consts, (hipStream_t)stream));
@@ -314,8 +316,11 @@ extern "C" int uavenv_rollout(UavEnv* e, int32_t num_steps, int32_t policy, cons
     if (policy == UAVENV_POLICY_ACTIONS && !actions_dev) return fail(e, UAVENV_E_INVALID, "actions_dev is NULL");
     if (e->aux_out != nullptr && num_steps > e->aux_capacity)
         return fail(e, UAVENV_E_INVALID, "rollout of more steps than the attached aux output holds ([K][E][4] blocks): detach it or attach a larger one");
-    StepArgs a{actions_dev, actions_out, obs, rew, rew32, done, term, e->num_envs,
-               e->term_pool, e->term_counter, nullptr, e->term_rows, policy, e->aux_out, nullptr, nullptr, 0, e->write_through ? 1 : 0};   // aux [K][E][4] carries the tickets
+    StepArgs a{};
+    a.actions = actions_dev; a.num_envs = e->num_envs; a.policy = policy; a.hint_in = nullptr;
+    a.out.actions_out = actions_out; a.out.obs = obs; a.out.reward = rew; a.out.reward32 = rew32; a.out.done = done; a.out.term_obs = term;
+    a.out.term_pool = e->term_pool; a.out.term_counter = e->term_counter; a.out.term_index = nullptr; a.out.term_rows = e->term_rows;
+    a.out.aux = e->aux_out; a.out.write_through = e->write_through ? 1 : 0;       // aux [K][E][4] carries the tickets
     HIP_TRY(e, launch_rollout(e->G, e->padded_envs, e->consts, e->dev_consts, e->ptrs, a, num_steps, e->default_consts, (hipStream_t)stream));
     return UAVENV_OK;
 }

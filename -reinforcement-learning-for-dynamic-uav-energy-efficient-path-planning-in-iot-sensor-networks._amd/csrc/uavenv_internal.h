@@ -81,35 +81,43 @@ struct Ptrs {
 constexpr uint64_t kOffPosX = 0, kOffPosY = 4, kOffBuffer = 8, kOffGen = 16, kOffTx = 24, kOffLost = 32, kOffAvg = 40,
                    kOffFlags = 48, kSensorBytesPerLane = 52;
 
-struct StepArgs {
-    const int32_t* actions;     // nullptr => in-kernel random policy
+// Where a step puts its results: ONE contiguous block of the argument struct, so that the kernels fetch all of it with a
+// single wide scalar load (load_out_args) instead of one scalar load + wait per pointer at the point of use.
+struct OutArgs {
     int32_t* actions_out;
     float* obs;
     double* reward;
     float* reward32;
     uint8_t* done;
     float* term_obs;
-    int32_t num_envs;           // E (arrays are padded to a whole number of workgroups)
     // optional terminal-observation pool (uavenv_set_terminal_pool): a truncating env takes the ticket
     // t = atomicAdd(term_counter, 1), writes its terminal row to term_pool[t % term_rows] and the row index to
     // term_index[env] (-1 if not done); the ticket itself goes into the aux block
     float* term_pool;
     uint32_t* term_counter;
     int32_t* term_index;
-    int32_t term_rows;
-    int32_t policy;             // UAVENV_POLICY_*
     float* aux;                 // optional [E][4] = (action, reward, done as float; terminal ticket or -1 as int32 bits):
                                 // the packed remainder of a transition block, so that replay insertion needs no pack kernel
+    uint32_t* hint_out;         // null unless the random policy writes next-step hints
+    int32_t term_rows;
+    int32_t write_through;      // observation and sensor-state stores as `sc1` write-through stores (batches that fill the chip: the
+                                // kernel boundary then has no dirty L2 lines to write back); any value gives the same results
+};
+static_assert(sizeof(OutArgs) == 96, "OutArgs is loaded as 24 dwords");
+
+struct StepArgs {
+    const int32_t* actions;     // nullptr => in-kernel random policy
+    int32_t num_envs;           // E (arrays are padded to a whole number of workgroups)
+    int32_t policy;             // UAVENV_POLICY_*
     // SIMD load balancing (a pure scheduling hint: any value gives the same results).  balance != 0: the wavefronts of
     // a workgroup take its environments collect-actions-first, so collect steps (1.6x the work of a move) spread evenly
     // over the CU's SIMDs.  The "is a collect" bits come from `actions`, or for the in-kernel random policy from
     // hint_in[wave unit] -- written by the PREVIOUS launch into its hint_out (double-buffered by the host: a launch never
     // writes the buffer its own wavefronts read).
     const uint32_t* hint_in;    // never null (one word per padded environment)
-    uint32_t* hint_out;         // null unless the random policy writes next-step hints
     int32_t balance;
-    int32_t write_through;      // observation and sensor-state stores as `sc1` write-through stores (batches that fill the chip: the
-                                // kernel boundary then has no dirty L2 lines to write back); any value gives the same results
+    int32_t reserved;
+    OutArgs out;
 };
 
 struct ResetArgs {

@@ -30,7 +30,7 @@ namespace uavenv {
 // timing-only ablation builds (tools/exp.sh "exitK=-DUAV_ABL_EXIT=K"): the step ends after phase K; `val` keeps what the phases
 // so far computed alive.  The kernel time of successive K's shows what each phase adds to a LAUNCH (overlap included).
 #ifdef UAV_ABL_EXIT
-#define UAV_EXIT_AT(k, val) do { if (UAV_ABL_EXIT == (k)) { if (gl == 0 && a.hint_out != nullptr) a.hint_out[env] = (uint32_t)(val); \
+#define UAV_EXIT_AT(k, val) do { if (UAV_ABL_EXIT == (k)) { if (gl == 0 && a.out.hint_out != nullptr) a.out.hint_out[env] = (uint32_t)(val); \
                                                             live = false; next_word = 0u; action_out = 0; return; } } while (0)
 #else
 #define UAV_EXIT_AT(k, val) do {} while (0)
@@ -70,22 +70,32 @@ typedef const __attribute__((address_space(4))) Consts& CRef;
 typedef const __attribute__((address_space(4))) int32_t& CI32;
 struct DefaultConsts {
     CRef m;
-    const __attribute__((address_space(4))) uint64_t& seed;
-    CI32 max_steps, fps, obs_dim, obs_slots, use_ema, max_tries, n_grid_choices;
-    const __attribute__((address_space(4))) uint32_t& flags;
+    // the integers every step needs (step limit, observation shape, EMA switch, flags) sit side by side in the block and are
+    // fetched HERE with one scalar load of 8 dwords, together with the wave's first loads, instead of one load + wait each where
+    // they are used; `seed` comes from the caller (a preloaded kernel argument in the step kernel)
+    uint64_t seed;
+    int32_t max_steps, fps, obs_dim, obs_slots, use_ema;
+    uint32_t flags;
+    CI32 max_tries, n_grid_choices;
     const __attribute__((address_space(4))) int32_t (&gw)[8];
     const __attribute__((address_space(4))) int32_t (&gh)[8];
     const __attribute__((address_space(4))) double (&inv_small)[65];
 #include "uavenv_default_consts.inc"
-    __device__ __forceinline__ explicit DefaultConsts(CRef k)
-        : m(k), seed(k.seed), max_steps(k.max_steps), fps(k.fps), obs_dim(k.obs_dim), obs_slots(k.obs_slots), use_ema(k.use_ema),
-          max_tries(k.max_tries), n_grid_choices(k.n_grid_choices), flags(k.flags), gw(k.gw), gh(k.gh), inv_small(k.inv_small) {}
+    __device__ __forceinline__ DefaultConsts(CRef k, uint64_t seed_)
+        : m(k), seed(seed_), max_tries(k.max_tries), n_grid_choices(k.n_grid_choices), gw(k.gw), gh(k.gh), inv_small(k.inv_small) {
+        static_assert(offsetof(Consts, flags) - offsetof(Consts, max_steps) == 20, "max_steps .. flags must be six adjacent words");
+        const __attribute__((address_space(4))) uint32_t* wp = (const __attribute__((address_space(4))) uint32_t*)&k.max_steps;
+        uint32_t w[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) w[i] = wp[i];
+        max_steps = (int32_t)w[0]; fps = (int32_t)w[1]; obs_dim = (int32_t)w[2]; obs_slots = (int32_t)w[3]; use_ema = (int32_t)w[4]; flags = w[5];
+    }
 };
 template <typename T> constexpr bool kIsDefaultConsts = false;
 template <> constexpr bool kIsDefaultConsts<DefaultConsts> = true;
 template <bool kDefC> struct ConstsSel;
-template <> struct ConstsSel<false> { static __device__ __forceinline__ CRef make(CRef k) { return k; } };
-template <> struct ConstsSel<true> { static __device__ __forceinline__ DefaultConsts make(CRef k) { return DefaultConsts(k); } };
+template <> struct ConstsSel<false> { static __device__ __forceinline__ CRef make(CRef k, uint64_t) { return k; } };
+template <> struct ConstsSel<true> { static __device__ __forceinline__ DefaultConsts make(CRef k, uint64_t seed) { return DefaultConsts(k, seed); } };
 
 // ---------------------------------------------------------------------------------------------
 // lane-group primitives (G lanes of a wave64)
@@ -384,6 +394,18 @@ typedef float __attribute__((ext_vector_type(3))) f32x3;
 __device__ __forceinline__ void store3_wt(float* q, float a, float b, float c, bool wt) {
     if (wt) { f32x3 v = {a, b, c}; asm volatile("global_store_dwordx3 %0, %1, off sc1" :: "v"(q), "v"(v) : "memory"); }
     else { struct __attribute__((packed, aligned(4))) P3 { float a, b, c; }; P3 w{a, b, c}; *reinterpret_cast<P3*>(q) = w; }
+}
+
+// The output block of the argument struct in ONE wide scalar load (24 dwords -> s_load_dwordx16 + x8) when the struct is
+// read in place from the kernarg segment: the step used to fetch each pointer where it was needed, a dozen dependent
+// "s_load, s_waitcnt" round trips (56-165 cycles each) in a row between the truncation test and the stores.
+template <typename A> __device__ __forceinline__ OutArgs load_out_args(const A& a) { return a.out; }
+template <> __device__ __forceinline__ OutArgs load_out_args(const __attribute__((address_space(4))) StepArgs& a) {
+    union { OutArgs o; uint32_t w[24]; } u;
+    const __attribute__((address_space(4))) uint32_t* wp = (const __attribute__((address_space(4))) uint32_t*)&a.out;
+#pragma unroll
+    for (int i = 0; i < 24; i++) u.w[i] = wp[i];
+    return u.o;
 }
 
 // per-lane sensor registers
@@ -806,10 +828,11 @@ __device__ __forceinline__ uint32_t hint_tag(uint32_t episode, uint32_t step) { 
 template <int G, bool kLean, bool kRegs = false, typename RecPtr = UavEnvRecord*, typename CT = Consts, typename P = Ptrs, typename A = StepArgs>
 __device__ __forceinline__ void step_once(const CT& c, const P& p, const A& a, uint32_t env, bool in_batch,
                                           RecPtr rec, UavEnvRecord* rec_out, Sensor& s, bool& wrote_pos, bool& live, uint32_t& dirty, uint32_t& status_or,
-                                          int& action_out, uint32_t& next_word, uint32_t hint_word = 0u, size_t row_offset = 0) {
+                                          int& action_out, uint32_t& next_word, int& wt_out, uint32_t hint_word = 0u, size_t row_offset = 0) {
     const int gl = group_lane<G>();
     // outputs of fused rollouts are [K][E][...] blocks: row = k * E + env (k = 0 for the single-step kernel)
     const size_t out = row_offset + env;
+    wt_out = 0;
     UAV_PHASE(0);
     UAV_EXIT_AT(0, env);
     Env e = load_env<G>(rec);
@@ -822,7 +845,6 @@ __device__ __forceinline__ void step_once(const CT& c, const P& p, const A& a, u
     if (UAV_POLICY(a) >= UAVENV_POLICY_NEAREST) {                    // heuristic baseline evaluated on device
         const float zP = draw_policy_noise<G, kLean>(c, p, e.env_index, e.episode, env, in_batch, step);
         action = uni<G>(policy_action<G>(c, s, e, act, a.policy, zP));
-        if (a.actions_out != nullptr && in_batch && gl == 0) a.actions_out[out] = action;
     } else if (UAV_POLICY(a) == UAVENV_POLICY_ACTIONS) action = uni<G>(in_batch ? a.actions[out] : 0);
     else {                                                       // uniform-random policy (Philox call 3)
 #ifdef UAV_ABL_CHEAPACTION   // timing-only ablation build: no Philox on the scalar unit for the action / the hint
@@ -839,7 +861,6 @@ __device__ __forceinline__ void step_once(const CT& c, const P& p, const A& a, u
             action = word_ok ? (int)(hint_word & 7u) : drawn;
         }
 #endif
-        if (a.actions_out != nullptr && in_batch && gl == 0) a.actions_out[out] = action;
     }
     const bool is_c = action == 4;
     const bool is_m = (action >= 0) & (action <= 3);
@@ -871,6 +892,9 @@ __device__ __forceinline__ void step_once(const CT& c, const P& p, const A& a, u
         loss = act ? l : 0.0;
     }
     const double step_data_loss = gsum<G>(loss);
+    // Every loaded row is "used" here, while only the loads are in flight: the compiler then never has to cover a load result it
+    // cannot prove consumed with an `s_waitcnt vmcnt(0)` between the final stores (where it would wait for the stores as well).
+    asm volatile("" :: "v"(s.avg), "v"(s.tx), "v"(s.flags), "v"(s.sx), "v"(s.sy));
     UAV_PHASE(2);
     UAV_EXIT_AT(2, __double2loint(step_data_loss) + __double2loint(s.tx + s.avg) + (int)s.flags + (int)s.sx + (int)s.sy);
 
@@ -1076,31 +1100,33 @@ __device__ __forceinline__ void step_once(const CT& c, const P& p, const A& a, u
     UAV_EXIT_AT(5, (uint32_t)__ballot(det + z.zD > -80.0) + (uint32_t)__ballot(z.zE + (float)s.b > 0.f) + __double2loint(reward) + visited_cnt);
 
     // ---- observation of the stepped state (side effect: ADR EMA) -------------------------------
+    const OutArgs o = load_out_args(a);                 // every output pointer of the step: one wide scalar load
+    wt_out = o.write_through;
     const bool auto_reset = (UAV_FLAGS(c) & UAVENV_FLAG_AUTO_RESET) != 0;
     const bool do_reset = truncated & auto_reset;
     int term_ticket = -1;         // value of the terminal-pool counter when this step claimed its row (row = ticket mod rows)
     {
         float* dst = nullptr;
         if (in_batch) {
-            if (do_reset) dst = a.term_obs ? a.term_obs + out * (size_t)c.obs_dim : nullptr;
-            else dst = a.obs ? a.obs + out * (size_t)c.obs_dim : nullptr;
+            if (do_reset) dst = o.term_obs ? o.term_obs + out * (size_t)c.obs_dim : nullptr;
+            else dst = o.obs ? o.obs + out * (size_t)c.obs_dim : nullptr;
         }
-        if (a.term_pool != nullptr) {          // kernel-uniform: terminal rows go to a compact pool instead
+        if (o.term_pool != nullptr) {          // kernel-uniform: terminal rows go to a compact pool instead
             int row = -1;
             if (__any(do_reset & in_batch)) {
                 uint32_t t = 0u;
-                if (do_reset & in_batch & (gl == 0)) t = atomicAdd(a.term_counter, 1u);
+                if (do_reset & in_batch & (gl == 0)) t = atomicAdd(o.term_counter, 1u);
                 t = gshfl<G>(t, 0);
                 if (do_reset & in_batch) {
                     term_ticket = (int)(t & 0x7FFFFFFFu);
-                    row = (int)(t % (uint32_t)a.term_rows);
-                    dst = a.term_pool + (size_t)row * (size_t)c.obs_dim;
+                    row = (int)(t % (uint32_t)o.term_rows);
+                    dst = o.term_pool + (size_t)row * (size_t)c.obs_dim;
                 }
             }
-            if (in_batch && gl == 0 && a.term_index != nullptr) a.term_index[out] = row;
+            if (in_batch && gl == 0 && o.term_index != nullptr) o.term_index[out] = row;
         }
         observe<G, kLean>(c, s, n, e.gw, e.gh, e.inv_w, e.inv_h, e.ux, e.uy, e.battery, act, true, det, z.zD, z.zE, dst,
-                          a.write_through != 0);   // :488
+                          o.write_through != 0);   // :488
     }
 
     UAV_EXIT_AT(6, (uint32_t)__ballot(s.avg > -80.0) + __double2loint(reward) + visited_cnt + (int)s.flags);
@@ -1148,10 +1174,11 @@ __device__ __forceinline__ void step_once(const CT& c, const P& p, const A& a, u
     r.episode_return += reward;
 
     if (in_batch && gl == 0) {
-        if (a.reward) a.reward[out] = reward;
-        if (a.reward32) a.reward32[out] = (float)reward;
-        if (a.done) a.done[out] = truncated ? 1 : 0;
-        if (a.aux) reinterpret_cast<float4*>(a.aux)[out] = make_float4((float)action, (float)reward, truncated ? 1.0f : 0.0f,
+        if (o.actions_out != nullptr && UAV_POLICY(a) != UAVENV_POLICY_ACTIONS) o.actions_out[out] = action;
+        if (o.reward) o.reward[out] = reward;
+        if (o.reward32) o.reward32[out] = (float)reward;
+        if (o.done) o.done[out] = truncated ? 1 : 0;
+        if (o.aux) reinterpret_cast<float4*>(o.aux)[out] = make_float4((float)action, (float)reward, truncated ? 1.0f : 0.0f,
                                                                     __int_as_float(term_ticket));
     }
 
@@ -1185,9 +1212,9 @@ __device__ __forceinline__ void step_once(const CT& c, const P& p, const A& a, u
         if (UAV_FLAGS(c) & UAVENV_FLAG_FAR_START) far_start<G>(c, s, r, act, do_reset);
         if (do_reset) { r.uav_x = r.start_x; r.uav_y = r.start_y; }
         double det0 = rssi_deterministic(c, r.uav_x, r.uav_y, s.sx, s.sy);
-        float* dst = (in_batch && a.obs) ? a.obs + out * (size_t)c.obs_dim : nullptr;
+        float* dst = (in_batch && o.obs) ? o.obs + out * (size_t)c.obs_dim : nullptr;
         observe<G, kLean>(c, s, r.num_sensors, r.grid_w, r.grid_h, r.inv_grid_w, r.inv_grid_h, r.uav_x, r.uav_y, r.battery, act, do_reset, det0, zD, zE, dst,
-                          a.write_through != 0);
+                          o.write_through != 0);
         if (UAV_FLAGS(c) & UAVENV_FLAG_PROX_SHAPING) {
             double d0 = dist_nearest_with_data<G>(s, act, r.uav_x, r.uav_y);
             if (do_reset) r.prev_dist_nearest = d0;
@@ -1239,7 +1266,7 @@ __device__ __forceinline__ void step_once(const CT& c, const P& p, const A& a, u
         const uint32_t na = (uint32_t)random_action(w3n);
 #endif
         next_word = na | hint_tag(r.episode, ns);
-        if (!kRegs && a.hint_out != nullptr && gl == 0) a.hint_out[env] = next_word;
+        if (!kRegs && o.hint_out != nullptr && gl == 0) o.hint_out[env] = next_word;
     }
     UAV_PHASE(7);
 
@@ -1253,21 +1280,24 @@ template <int G, bool kLean, int kWaves, bool kDefC>
 __global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kernel(
         // The first seven arguments repeat fields of the two structs: they are the pointers the first loads of a wave
         // need, and as leading scalar arguments they arrive PRELOADED in SGPRs with the wave launch (gfx950 kernarg
-        // preload, -mllvm -amdgpu-kernarg-preload-count=7 in build.py) instead of behind a kernarg-segment round trip.
+        // preload, -mllvm -amdgpu-kernarg-preload-count=8 in build.py: 16 SGPRs, the maximum) instead of behind a kernarg-segment
+        // round trip.  launch_word = num_envs | grid blocks << 32 | balance << 63 (gridDim.x itself would be a load from the hidden
+        // arguments in front of everything else); seed = the Philox key.
         const Consts* cptr, char* sensor_base, uint64_t lanes, UavEnvRecord* rec_base, const uint32_t* hint_in,
-        const int32_t* actions, uint64_t balance_and_envs, Ptrs p_in, StepArgs a_in) {
+        const int32_t* actions, uint64_t launch_word, uint64_t seed, Ptrs p_in, StepArgs a_in) {
     // The two structs are NOT taken from the parameters (that would load every field at the kernel entry and spill
     // them): they are read in place from the kernarg segment, field by field where used, like the constants block.
     struct Kernargs { const Consts* cptr; char* sensor_base; uint64_t lanes; UavEnvRecord* rec; const uint32_t* hint_in;
-                      const int32_t* actions; uint64_t be; Ptrs p; StepArgs a; };
+                      const int32_t* actions; uint64_t launch_word; uint64_t seed; Ptrs p; StepArgs a; };
     typedef const __attribute__((address_space(4))) unsigned char* KA;
     KA ka = (KA)__builtin_amdgcn_kernarg_segment_ptr();
     const __attribute__((address_space(4))) Ptrs& p = *(const __attribute__((address_space(4))) Ptrs*)(ka + offsetof(Kernargs, p));
     const __attribute__((address_space(4))) StepArgs& a = *(const __attribute__((address_space(4))) StepArgs*)(ka + offsetof(Kernargs, a));
     const SensorBase sb{sensor_base, lanes};
-    const int32_t num_envs = (int32_t)(uint32_t)balance_and_envs;
-    const bool balance = (balance_and_envs >> 32) != 0ull;
-    decltype(auto) c = ConstsSel<kDefC>::make(*(const __attribute__((address_space(4))) Consts*)(cptr));
+    const int32_t num_envs = (int32_t)(uint32_t)launch_word;
+    const bool balance = (launch_word >> 63) != 0ull;
+    const uint32_t grid_blocks = (uint32_t)(launch_word >> 32) & 0x7FFFFFFFu;
+    decltype(auto) c = ConstsSel<kDefC>::make(*(const __attribute__((address_space(4))) Consts*)(cptr), seed);
 #ifdef UAVENV_STAMPS
     const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1292,7 +1322,7 @@ __global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kerne
     constexpr int kPool = UAV_POOL, kXcds = 8, kWordsPerLane = kPool * 16 / 64;   // pool units = 16 * kPool, 64 per word slot
     const uint32_t span0 = blockIdx.x - blockIdx.x % (kPool * kXcds);             // kPool * 8 workgroups = 8 pools
     const uint32_t pool_b0 = span0 + blockIdx.x % kXcds;                          // first member of this workgroup's pool
-    const bool pooled = (G == 64) & (kWaves == 16) & (span0 + kPool * kXcds <= gridDim.x);
+    const bool pooled = (G == 64) & (kWaves == 16) & (span0 + kPool * kXcds <= grid_blocks);
     bool unit_is_global = false;
     uint32_t pool_word = 0u;
     bool have_pool_word = false;
@@ -1345,7 +1375,7 @@ __global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kerne
         // hint words instead of running past the array's end: any bits give a valid schedule).
         typedef const __attribute__((address_space(4))) uint32_t* CU32;
         constexpr int kWords = kWaves * kEnvsPerWave;
-        const bool from_actions = (actions != nullptr) & ((int)(blockIdx.x * kWords) + kWords <= (int)(uint32_t)balance_and_envs);
+        const bool from_actions = (actions != nullptr) & ((int)(blockIdx.x * kWords) + kWords <= num_envs);
         CU32 src = (from_actions ? (CU32)actions : (CU32)hint_in) + (size_t)blockIdx.x * kWords;
         uint32_t mask = 0u;
 #pragma unroll
@@ -1363,6 +1393,7 @@ __global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kerne
     const bool in_batch = env < (uint32_t)num_envs;
     Sensor s;
     load_sensor<G>(sb, idx, s);
+    int wt_word = 0;                                  // StepArgs::write_through, handed back by step_once (it loads the output block)
     bool wrote_pos = false, live = false;
     uint32_t status_or = 0u, dirty = 0u;
     int action = 0;
@@ -1376,10 +1407,10 @@ __global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kerne
     if (G == 64) {
         typedef const __attribute__((address_space(4))) UavEnvRecord* ScalarRec;
         step_once<G, kLean, false, ScalarRec>(c, p, a, env, in_batch, (ScalarRec)(rec_base + env), rec_base + env, s, wrote_pos,
-                                              live, dirty, status_or, action, next_word, hint_word);
+                                              live, dirty, status_or, action, next_word, wt_word, hint_word);
     } else
-        step_once<G, kLean>(c, p, a, env, in_batch, rec_base + env, rec_base + env, s, wrote_pos, live, dirty, status_or, action, next_word, hint_word);
-    store_sensor<G>(sb, idx, s, wrote_pos, live, dirty, a.write_through != 0);
+        step_once<G, kLean>(c, p, a, env, in_batch, rec_base + env, rec_base + env, s, wrote_pos, live, dirty, status_or, action, next_word, wt_word, hint_word);
+    store_sensor<G>(sb, idx, s, wrote_pos, live, dirty, wt_word != 0);
     if (gl == 0 && status_or) atomicOr(p.status, status_or);
 #ifdef UAVENV_STAMPS
     if (p.stamps != nullptr && (threadIdx.x & 63u) == 0) {
@@ -1416,6 +1447,7 @@ __global__ __launch_bounds__(kSmallBlockThreads, (G == 64 ? 4 : 2)) void uav_rol
     load_sensor<G>(p, idx, s);
     UavEnvRecord rr = p.rec[env];
     bool wrote_pos = false, live = false;
+    int wt_word = 0;
     uint32_t status_or = 0u, dirty = 0u;
     const size_t E = (size_t)a.num_envs;
     uint32_t carried_word = 0u;      // the random policy's next action, handed from step to step (0: draw it)
@@ -1425,16 +1457,17 @@ __global__ __launch_bounds__(kSmallBlockThreads, (G == 64 ? 4 : 2)) void uav_rol
         // out of the loop and the SGPR file spills into VGPR lanes (and those into scratch).
         const Consts* cp = cptr;
         asm volatile("" : "+s"(cp));
-        decltype(auto) ck = ConstsSel<kDefC>::make(*(const __attribute__((address_space(4))) Consts*)(cp));
+        CRef ckm = *(const __attribute__((address_space(4))) Consts*)(cp);
+        decltype(auto) ck = ConstsSel<kDefC>::make(ckm, ckm.seed);
         KA ka = ka0;                              // same for the argument structs
         asm volatile("" : "+s"(ka));
         const __attribute__((address_space(4))) Ptrs& pk = *(const __attribute__((address_space(4))) Ptrs*)(ka + offsetof(Kernargs, p));
         const __attribute__((address_space(4))) StepArgs& ak = *(const __attribute__((address_space(4))) StepArgs*)(ka + offsetof(Kernargs, a));
         // every step writes block k of the [K][E][...] outputs: the row offset k * E goes to step_once, the argument
         // structs stay untouched (no per-step copies of nine pointers competing for SGPRs)
-        step_once<G, kLean, true>(ck, pk, ak, env, in_batch, &rr, &rr, s, wrote_pos, live, dirty, status_or, action, carried_word, carried_word, (size_t)k * E);
+        step_once<G, kLean, true>(ck, pk, ak, env, in_batch, &rr, &rr, s, wrote_pos, live, dirty, status_or, action, carried_word, wt_word, carried_word, (size_t)k * E);
     }
-    store_sensor<G>(p, idx, s, wrote_pos, live, dirty, a.write_through != 0);
+    store_sensor<G>(p, idx, s, wrote_pos, live, dirty, wt_word != 0);
     if (gl == 0) p.rec[env] = rr;
     if (gl == 0 && status_or) atomicOr(p.status, status_or);
 }
@@ -1568,9 +1601,9 @@ hipError_t launch_step(int Gw, int padded_envs, const Consts& c, const Consts* d
     const bool big = step_uses_big_workgroups(Gw, padded_envs);
     const int wg_waves = big ? kBlockThreads / 64 : kSmallBlockThreads / 64;
     dim3 block(wg_waves * 64), grid((unsigned)(waves / wg_waves));
-    const uint64_t be = ((uint64_t)(uint32_t)a.balance << 32) | (uint64_t)(uint32_t)a.num_envs;
+    const uint64_t be = ((uint64_t)(a.balance != 0) << 63) | ((uint64_t)grid.x << 32) | (uint64_t)(uint32_t)a.num_envs;
 #define UAV_STEP_LAUNCH(LEAN, WV, DEFC) uav_step_kernel<G, LEAN, WV, DEFC><<<grid, block, lds_bytes(Gw, c), s>>>( \
-        dc, p.sensor_base, p.lanes, p.rec, a.hint_in, a.actions, be, p, a)
+        dc, p.sensor_base, p.lanes, p.rec, a.hint_in, a.actions, be, c.seed, p, a)
     if (lean_ok(c, p, a) && default_consts) {       // the reference configuration: constants as instruction literals
         if (big) { UAV_DISPATCH_G(Gw, (UAV_STEP_LAUNCH(true, kBlockThreads / 64, true))); }
         else { UAV_DISPATCH_G(Gw, (UAV_STEP_LAUNCH(true, kSmallBlockThreads / 64, true))); }

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."
 PKG="./-reinforcement-learning-for-dynamic-uav-energy-efficient-path-planning-in-iot-sensor-networks._amd"
 mkdir -p tools/_exp
 rm -f tools/_exp/lib_*.so
-FLAGS="-O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -std=c++17 -Wno-bitwise-instead-of-logical -Wno-unused-variable -mllvm -amdgpu-kernarg-preload-count=7"
+FLAGS="-O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -std=c++17 -Wno-bitwise-instead-of-logical -Wno-unused-variable -mllvm -amdgpu-kernarg-preload-count=8"
 names=""
 for v in "$@"; do
   n="${v%%=*}"; f="${v#*=}"
