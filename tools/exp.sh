@@ -2,7 +2,7 @@
 # Build container + GPU box: A/B timing of step-kernel variants.  Each "name=flags" argument is compiled HERE (hipcc
 # cross-compiles) into gpurun_out-free tools/_exp/lib_<name>.so (they travel with the snapshot), then every variant is
 # timed on an MI355X at 256 and 4096 environments x 50 sensors (uavenv_time_steps, 3 x 1000 launches each).
-#   tools/exp.sh base= nostate=-DUAV_ABL_NOSTATE ...
+#   tools/exp.sh base= nostate=-DUAV_ABL_NOSTATE head=@/tmp/lib_head.so ...
 set -e
 cd "$(dirname "$0")/.."
 PKG="./-reinforcement-learning-for-dynamic-uav-energy-efficient-path-planning-in-iot-sensor-networks._amd"
@@ -13,6 +13,7 @@ names=""
 for v in "$@"; do
   n="${v%%=*}"; f="${v#*=}"
   names="$names $n"
+  if [ "${f#@}" != "$f" ]; then cp "${f#@}" tools/_exp/lib_$n.so; continue; fi     # name=@/path/lib.so: a library built earlier
   ( /opt/rocm/bin/hipcc $FLAGS $f -o tools/_exp/lib_$n.so "$PKG/csrc/uavenv_kernels.hip" "$PKG/csrc/uavenv_capi.hip" "$PKG/csrc/uavenv_attention.hip" 2> tools/_exp/build_$n.log || echo "BUILD FAILED $n" ) &
 done
 wait

@@ -26,7 +26,23 @@ for E in [int(x) for x in os.environ.get("ES", "256,4096").split(",")]:
     f0.record()
     for _ in range(50): env.rollout(F, obs_out=slab)
     f1.record(); torch.cuda.synchronize()
-    out.append("E=%%5d step %%6.2f us (min %%.2f)  rollout/16 %%6.2f us/step" %% (E, ts[2] * 1e3, ts[0] * 1e3, f0.elapsed_time(f1) / 50 / F * 1e3))
+    # given actions (the acting path of a learner): 64 launches replayed as one HIP graph, a fresh action array per step
+    acts = torch.randint(0, 5, (64, E), dtype=torch.int32, device=env.device)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for k in range(3): env.step(acts[k])
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for k in range(64): env.step(acts[k])
+        for _ in range(3): g.replay()
+        side.synchronize()
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record(side)
+        for _ in range(20): g.replay()
+        a1.record(side); side.synchronize()
+    t_act = a0.elapsed_time(a1) / 20 / 64 * 1e3
+    out.append("E=%%5d step %%6.2f us (min %%.2f)  given actions %%6.2f us  rollout/16 %%6.2f us/step" %% (E, ts[2] * 1e3, ts[0] * 1e3, t_act, f0.elapsed_time(f1) / 50 / F * 1e3))
     env.close()
 print("%%-14s %%s" %% (sys.argv[2], "   |   ".join(out)))
 ''' % ROOT
