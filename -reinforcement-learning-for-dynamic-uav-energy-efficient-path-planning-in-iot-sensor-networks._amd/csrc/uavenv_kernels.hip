@@ -1294,6 +1294,14 @@ __global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kerne
     const __attribute__((address_space(4))) Ptrs& p = *(const __attribute__((address_space(4))) Ptrs*)(ka + offsetof(Kernargs, p));
     const __attribute__((address_space(4))) StepArgs& a = *(const __attribute__((address_space(4))) StepArgs*)(ka + offsetof(Kernargs, a));
     const SensorBase sb{sensor_base, lanes};
+    // Touch the four kernarg cache lines behind the preloaded words with the wave's first instructions, so that the loads that
+    // need them later (policy word, output block, record epilogue) find them in the scalar cache: -0.08 us per launch when the
+    // launches are graph nodes (8.14 -> 8.06 us at 4096 x 50, 6.02 -> 5.96 at 256), nothing for eager launches.  The four
+    // destination registers stay allocated until the drain below, which sits where the wave waits for its state anyway.
+    static_assert(sizeof(Kernargs) <= 0x140 && sizeof(Kernargs) > 0x100, "the prefetch below covers kernarg lines 1..4");
+    uint32_t pf0, pf1, pf2, pf3;
+    asm volatile("s_load_dword %0, %4, 0x40\n\ts_load_dword %1, %4, 0x80\n\ts_load_dword %2, %4, 0xc0\n\ts_load_dword %3, %4, 0x100"
+                 : "=&s"(pf0), "=&s"(pf1), "=&s"(pf2), "=&s"(pf3) : "s"(ka));
     const int32_t num_envs = (int32_t)(uint32_t)launch_word;
     const bool balance = (launch_word >> 63) != 0ull;
     const uint32_t grid_blocks = (uint32_t)(launch_word >> 32) & 0x7FFFFFFFu;
@@ -1393,6 +1401,7 @@ __global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kerne
     const bool in_batch = env < (uint32_t)num_envs;
     Sensor s;
     load_sensor<G>(sb, idx, s);
+    asm volatile("s_waitcnt lgkmcnt(0)" :: "s"(pf0), "s"(pf1), "s"(pf2), "s"(pf3));    // (drains the kernarg prefetch above)
     int wt_word = 0;                                  // StepArgs::write_through, handed back by step_once (it loads the output block)
     bool wrote_pos = false, live = false;
     uint32_t status_or = 0u, dirty = 0u;

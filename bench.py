@@ -156,7 +156,9 @@ def main():
     ap.add_argument("--sensors", type=int, default=50)
     ap.add_argument("--grid", type=int, default=500)
     ap.add_argument("--exchange", choices=["auto", "none", "allgather"], default="auto")
-    ap.add_argument("--ring", type=int, default=128, help="replay-ring slots used by the bench (two chunks = two HIP graphs / collectives)")
+    ap.add_argument("--ring", type=int, default=128, help="replay-ring slots used by the bench (two chunks = two HIP graphs / collectives).  "
+                    "Measured at 4096 x 50 (2.6 MB per slot): 8.73 / 8.50 / 8.39 / 8.38 us per step for rings of 32 / 50 / 80 / 128 slots, "
+                    "8.95 for 250 and 500 -- a ring beyond the 256 MB Infinity Cache makes every output store miss it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of chunk by chunk")
     ap.add_argument("--launch", choices=["batch", "graph"], default="graph",
@@ -288,8 +290,8 @@ def main():
     run_steps(W, align=True)
     ring.drain()
 
-    def timed_region(with_events=False):
-        """EXACTLY K steps between two barrier + synchronize brackets; returns (wall s, enqueue s, device-event ms or None).
+    def timed_region(with_events=False, steps=None):
+        """EXACTLY K steps (or `steps`, for the diagnostic event region) between two barrier + synchronize brackets; returns (wall s, enqueue s, device-event ms or None).
         The regions that produce `value` record NO events: an event pair costs ~10 us of completion latency on an idle
         GPU (tools/bracket_probe.py: 22 us around an empty region with events, 3 us without), which is noise of the order
         of a step in a short region.  The device-event figure comes from one extra region that is not counted."""
@@ -300,7 +302,7 @@ def main():
         t0 = time.perf_counter()
         if with_events:
             ev0.record()                   # torch's current stream IS the stream the kernel is launched on
-        run_steps(K)
+        run_steps(K if steps is None else steps)
         t_enq = time.perf_counter() - t0
         if with_events:
             ev1.record()
@@ -326,9 +328,17 @@ def main():
     ev_ms = timed_region(with_events=True)[2]          # diagnostic only
     run_steps(0, align=True)
 
-    # Kernel-only launch duration, HIP events on the launch stream around back-to-back launches
-    # (measured on every rank, after the timed region so it cannot perturb it)
-    kern_ms = env.time_steps(min(K, 1000))
+    # The step kernel's average launch duration for `roofline`: HIP events on the launch stream around the bench's OWN launch
+    # path (the same graph replays into the ring), over a region long enough that the bracket's ~20 us do not show (a region
+    # of its own, not one that produces `value`: see timed_region).  rocprofv3's average for the kernel in the same command
+    # (profiles/*_kernel_stats.md) is the figure it has to agree with.  `back_to_back_ms` is the same kernel launched
+    # back-to-back from a C loop with one fixed observation buffer (no graph, no ring): what tools/exp.sh compares.
+    ev_steps = max(K, 1000)
+    if chunked:
+        ev_steps = -(-ev_steps // L) * L
+    kern_ms = timed_region(with_events=True, steps=ev_steps)[2] / ev_steps
+    run_steps(0, align=True)
+    back_to_back_ms = env.time_steps(min(K, 1000))
     torch.cuda.synchronize(dev)
 
     # Additional measurement for N > 1 (never `value`): the same K steps WITHOUT the exchange, every rank filling a ring of
@@ -411,7 +421,8 @@ def main():
                      "kernel": "uav_step_kernel<64, true, 16, true> (lane group 64, lean, 16-wave workgroups, default-config literals)",
                      "algorithmic_bytes_per_launch": per_launch_bytes,
                      "algorithmic_bytes_per_env_step": B, "avg_launch_ms": kern_ms,
-                     "timed_region_event_ms_per_step": ev_ms / K,
+                     "avg_launch_source": f"HIP events on the launch stream around {ev_steps} steps of this run's launch path",
+                     "timed_region_event_ms_per_step": ev_ms / K, "back_to_back_ms": back_to_back_ms,
                      "note": "path is VALU/latency bound (Philox + float64 physics per sensor), not HBM bound: "
                              "see DESIGN.md"},
         # what the launch is actually bound by, for context (not a roofline the contract asks for): the measured split of a wave's
