@@ -21,7 +21,9 @@ are exactly the transitions that carry the -5000 * unvisited / -1000 * starved t
 (reward_function.py:59-67).  A terminal row is addressed by its ticket = the value of the chunk's counter when
 the kernel claimed it (row = ticket mod T; `count` = the counter's final value travels with the section): a
 row has been overwritten by a later episode end of the same chunk iff count - ticket > T, which `_next_frame`
-reports as valid = False instead of handing out another environment's observation.  T defaults to E: every
+reports as valid = False instead of handing out another environment's observation.  The counter is never reset:
+it keeps counting through every recycling of its chunk (the slots holding tickets of an earlier cycle have left the
+sampling window by then), so a chunk's graph is nothing but its L step launches.  T defaults to E: every
 environment of the shard can end inside one chunk (they all start together: with the base configuration all
 environments truncate within ~60 steps of each other) without losing a row.
 """
@@ -150,10 +152,10 @@ class TransitionRing:
             w = dist.all_gather_into_tensor(out, inp.clone(), group=self.group, async_op=True)
         self._pending[c] = w
 
-    def _advance(self, n, zero_counts=True):
+    def _advance(self, n):
         """Move the head by n committed slots; gather every chunk that was completed; recycle the chunk the head
-        enters (its previous gather must be over, its terminal counter restarts at 0, its old slots leave the
-        sampling window)."""
+        enters (its previous gather must be over; its old slots leave the sampling window, and with them the tickets
+        of its previous cycle -- the terminal counter just keeps counting)."""
         for _ in range(n):
             slot = self.head
             c, j = self._cj(slot)
@@ -163,8 +165,6 @@ class TransitionRing:
             if self.head % self.L == 0:
                 nc = self.head // self.L
                 self.wait_chunk(nc)
-                if zero_counts:
-                    self._count[nc, self.rank] = 0
             self.size = min(self.size + 1, self.capacity - self.L + self.head % self.L)
         self.wait_slot(self.head)
 
@@ -196,7 +196,7 @@ class TransitionRing:
 
     # ---- launch-bound producer loops: one HIP graph per chunk -----------------------------------------------
     def capture_chunks(self, step_fn):
-        """Capture, for every chunk, "restart the terminal counter; L x (re-point outputs, `step_fn(obs_slot)`)" into one
+        """Capture, for every chunk, "L x (re-point outputs, `step_fn(obs_slot)`)" into one
         HIP graph (the head must stand at the start of a chunk).  `replay_chunk(graphs)` then costs one graph launch
         (plus the chunk's collective when ranks share the ring, issued from the host after the replay) instead of L
         Python -> ctypes -> hipLaunchKernel round trips of ~12 us each -- more than the step kernel itself at 4096
@@ -209,7 +209,6 @@ class TransitionRing:
             c = (head0 // self.L + k) % self.n_chunks
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._count[c, self.rank].zero_()
                 for j in range(self.L):
                     slot = c * self.L + j
                     self._point_env(slot)
@@ -224,10 +223,9 @@ class TransitionRing:
         assert self._env is not None and self.head % self.L == 0
         c = self.head // self.L
         self.wait_chunk(c)
-        self._count[c, self.rank].zero_()
         self._point_env(c * self.L)                     # terminal section of this chunk
         self._env.step_random_n(self.L, self._obs5[c, self.rank, 0], self.block, self._aux5[c, self.rank, 0], self.block)
-        self._advance(self.L, zero_counts=False)
+        self._advance(self.L)
         self._point_env()
 
     def replay_chunk(self, graphs):
@@ -236,7 +234,7 @@ class TransitionRing:
         assert self.head % self.L == 0
         self.wait_chunk(c)            # its previous gather (a full revolution ago) must be done before it is overwritten;
         graphs[c].replay()            # the gather of the chunk just before this one keeps running on the side stream
-        self._advance(self.L, zero_counts=False)      # the next chunk's graph restarts its own counter
+        self._advance(self.L)
         self._point_env()
 
     def drain(self):
