@@ -129,9 +129,24 @@ __device__ __forceinline__ float readlane(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-struct OpSum { template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return a + b; } };
-struct OpMax { template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return b > a ? b : a; } };
-struct OpMin { template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return b < a ? b : a; } };
+// kZeroFill: lanes a masked DPP step leaves out may see 0 (sum) -- otherwise they must see their own value (max / min)
+struct OpSum { static constexpr bool kZeroFill = true; template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return a + b; } };
+struct OpMax { static constexpr bool kZeroFill = false; template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return b > a ? b : a; } };
+struct OpMin { static constexpr bool kZeroFill = false; template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return b < a ? b : a; } };
+
+// DPP row broadcasts (gfx9): row_bcast15 hands lane 15 of every row to the NEXT row, row_bcast31 lane 31 to rows 2 and 3; the
+// row mask restricts which rows take it (the others keep `old`).
+constexpr int kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
+template <int CTRL, int ROWS, bool kZeroFill> __device__ __forceinline__ float dpp_rows(float v) {
+    const int x = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(kZeroFill ? 0 : x, x, CTRL, ROWS, 0xF, false));
+}
+template <int CTRL, int ROWS, bool kZeroFill> __device__ __forceinline__ double dpp_rows(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(kZeroFill ? 0 : lo, lo, CTRL, ROWS, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(kZeroFill ? 0 : hi, hi, CTRL, ROWS, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
 
 // all-lanes reduction over a lane group: 4 DPP steps inside each 16-lane row, then rows are
 // combined with one bpermute level (G = 32) or through SGPRs with v_readlane (G = 64: the group is
@@ -143,8 +158,11 @@ template <int G, typename T, typename Op> __device__ __forceinline__ T greduce(T
     v = op(v, dpp<kDppMirror>(v));
     if (G == 32) v = op(v, __shfl_xor(v, 16, 64));
     if (G == 64) {
-        T r0 = readlane(v, 0), r1 = readlane(v, 16), r2 = readlane(v, 32), r3 = readlane(v, 48);
-        v = op(op(r0, r1), op(r2, r3));
+        // rows r0..r3 -> (r0 op r1) in row 1, (r2 op r3) in row 3 -> ((r2 op r3) op (r0 op r1)) in row 3: the same tree as
+        // op(op(r0, r1), op(r2, r3)) (the operations commute exactly), two DPP steps and one lane read instead of four reads
+        v = op(v, dpp_rows<kDppRowBcast15, 0xA, Op::kZeroFill>(v));
+        v = op(v, dpp_rows<kDppRowBcast31, 0xC, Op::kZeroFill>(v));
+        v = readlane(v, 63);
     }
     return v;
 }
@@ -335,7 +353,7 @@ template <typename CT> __device__ __forceinline__ double calc_urgency(const CT& 
     double util = div_const(b, c.bmax, c.inv_bmax);
     double loss_rate = gen > 0 ? lost / gen : 0.0;
     double u = util * (1.0 + loss_rate * 10.0);
-    return u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
+    return __builtin_fmin(__builtin_fmax(u, 0.0), 1.0);     // np.clip; u is never NaN or -0.0 (b, lost >= 0, gen > 0)
 }
 
 // The per-environment values the step needs from its first instruction on.  When the lane group is the
@@ -881,15 +899,17 @@ __device__ __forceinline__ void step_once(const CT& c, const P& p, const A& a, u
     const double step_duration = is_c ? c.coll_dur : 1.0;
     double loss = 0.0;
     {
-        const double new_data = c.rate * step_duration;
+        // Selects replaced by arithmetic that gives the same bits: lanes beyond the sensor count generate nothing (their rows are
+        // 0 and stay 0: 0 + 0, min(0, Bmax), max(-Bmax, 0) = 0); the overflow is max(b' - Bmax, 0) -- positive exactly when
+        // b' > Bmax, and `lost + 0.0` is `lost` -- and the capped buffer min(b', Bmax).
+        const double new_data = act ? c.rate * step_duration : 0.0;
         const double potential = s.b + new_data;
-        const bool over = potential > c.bmax;
-        const double l = over ? potential - c.bmax : 0.0;
-        s.gen = act ? s.gen + new_data : s.gen;
-        s.b = act ? (over ? c.bmax : potential) : s.b;
-        s.lost = (act & over) ? s.lost + l : s.lost;
-        dirty |= (act & over) ? 2u : 0u;
-        loss = act ? l : 0.0;
+        const double l = __builtin_fmax(potential - c.bmax, 0.0);
+        s.gen = s.gen + new_data;
+        s.b = __builtin_fmin(potential, c.bmax);
+        s.lost = s.lost + l;
+        dirty |= (l > 0.0) ? 2u : 0u;
+        loss = l;
     }
     const double step_data_loss = gsum<G>(loss);
     // Every loaded row is "used" here, while only the loads are in flight: the compiler then never has to cover a load result it

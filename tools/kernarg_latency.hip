@@ -33,6 +33,8 @@ __global__ void probe(Big big, const uint32_t* buf, unsigned long long* out, uin
     }
 }
 
+__global__ void empty_kernel(Big big, uint32_t* sink) { if (big.w[0] == 12345u) sink[0] = 1; }
+
 static int report(const char* how, unsigned long long* out, int B) {
     std::vector<unsigned long long> h(B * 8);
     CHECK(hipMemcpy(h.data(), out, B * 8 * 8, hipMemcpyDeviceToHost));
@@ -67,5 +69,27 @@ int main() {
     for (int r = 0; r < 3; r++) CHECK(hipGraphLaunch(ge, s));
     CHECK(hipStreamSynchronize(s));
     if (report("graph replay (last of 50 nodes, third replay)", out, B)) return 1;
+    // the per-node floor: 200 EMPTY kernels of the step kernel's shape (256 workgroups x 1024 threads), as graph nodes and eagerly
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int shape = 0; shape < 2; shape++) {
+        const int wg = shape == 0 ? 1024 : 256, blocks = shape == 0 ? 256 : 64;
+        hipGraph_t g2; hipGraphExec_t ge2;
+        CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+        for (int it = 0; it < 200; it++) empty_kernel<<<blocks, wg, 0, s>>>(big, sink);
+        CHECK(hipStreamEndCapture(s, &g2));
+        CHECK(hipGraphInstantiate(&ge2, g2, nullptr, nullptr, 0));
+        for (int r = 0; r < 3; r++) CHECK(hipGraphLaunch(ge2, s));
+        CHECK(hipStreamSynchronize(s));
+        float ms = 0.f;
+        CHECK(hipEventRecord(e0, s));
+        for (int r = 0; r < 10; r++) CHECK(hipGraphLaunch(ge2, s));
+        CHECK(hipEventRecord(e1, s)); CHECK(hipEventSynchronize(e1)); CHECK(hipEventElapsedTime(&ms, e0, e1));
+        printf("empty kernel %d x %d: %.2f us per graph node", blocks, wg, ms / 2000 * 1e3);
+        CHECK(hipEventRecord(e0, s));
+        for (int it = 0; it < 2000; it++) empty_kernel<<<blocks, wg, 0, s>>>(big, sink);
+        CHECK(hipEventRecord(e1, s)); CHECK(hipEventSynchronize(e1)); CHECK(hipEventElapsedTime(&ms, e0, e1));
+        printf(", %.2f us per eager launch\n", ms / 2000 * 1e3);
+    }
     return 0;
 }
