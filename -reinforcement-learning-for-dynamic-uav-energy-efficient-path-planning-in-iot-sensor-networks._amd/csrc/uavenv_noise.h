@@ -2,7 +2,7 @@
 //
 // Replaces the reference's three process-global RNG streams (np.random.normal at
 // iot_sensors.py:192, stdlib random.random() at uav_env.py:549, gymnasium np_random.uniform at
-// uav_env.py:410) by Philox4x32-10 keyed by the 64-bit seed and addressed by
+// uav_env.py:410) by Philox4x32-7 (UAVENV_PHILOX_ROUNDS, include/uavenv.h) keyed by the 64-bit seed and addressed by
 //     counter = (global env index, episode, step, lane | call << 16).
 //
 //   call 0 (every step; step 0 = the observation built inside reset):
@@ -21,6 +21,7 @@
 // specification independently in oracle/uavenv_oracle.c).
 #pragma once
 #include <stdint.h>
+#include "../../include/uavenv.h"       // UAVENV_PHILOX_ROUNDS
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -59,7 +60,7 @@ UAV_HD Words4 noise_words(uint64_t seed, uint32_t env, uint32_t episode, uint32_
 #ifdef UAV_ABL_PHILOX      // timing-only ablation build (tools/ablate.py): fewer rounds for the per-lane draws only
     if (call <= 1u) return philox4x32<UAV_ABL_PHILOX>(env, episode, step, lane | (call << 16), (uint32_t)seed, (uint32_t)(seed >> 32));
 #endif
-    return philox4x32<10>(env, episode, step, lane | (call << 16), (uint32_t)seed, (uint32_t)(seed >> 32));
+    return philox4x32<UAVENV_PHILOX_ROUNDS>(env, episode, step, lane | (call << 16), (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
 UAV_HD float u24(uint32_t w) { return (float)(w >> 8) * 0x1p-24f; }      // [0,1), 24 bits, exact

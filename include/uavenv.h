@@ -128,7 +128,13 @@ enum {
     UAVENV_F_COUNT = 12
 };
 
-/* noise-tape slots (float [E][slots][stride]); NULL tape = in-kernel Philox4x32-10 */
+/* The in-kernel noise generator: Philox4x32 (Salmon et al., SC'11) with this many rounds.  7 is the smallest round count the
+ * authors report as passing BigCrush ("Crush-resistant"); 10 is Random123's default safety margin.  The three rounds cost
+ * 0.4 us of an 8 us step launch (24 multiply / xor instructions per lane and call), so the library uses 7 -- the oracle
+ * (oracle/uavenv_oracle.c) reads the same constant, tests/test_noise_spec.py pins both round counts to Random123's vectors. */
+#define UAVENV_PHILOX_ROUNDS 7
+
+/* noise-tape slots (float [E][slots][stride]); NULL tape = in-kernel Philox4x32-7 */
 enum { UAVENV_TAPE_ZA = 0, UAVENV_TAPE_ZB, UAVENV_TAPE_U, UAVENV_TAPE_ZC, UAVENV_TAPE_ZD, UAVENV_TAPE_ZE,
        UAVENV_TAPE_ZP,          /* in-range sample drawn by a heuristic policy before the step */
        UAVENV_TAPE_STEP_SLOTS };

@@ -109,6 +109,8 @@ def lib():
         L.orc_noise_action.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
         L.orc_noise_action.restype = C.c_int
         L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.orc_philox4x32.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32)]
+        L.orc_philox_rounds.restype = C.c_int
         L.orc_normal_pair.argtypes = [C.c_uint32, C.c_uint32, fp, fp]
         L.orc_run_random_policy.argtypes = [C.POINTER(OrcConfig), C.c_int, C.c_uint32, C.c_int, C.POINTER(_D)]
         L.orc_run_random_policy.restype = C.c_long
@@ -233,9 +235,10 @@ class OracleEnv:
         )
 
 
-def philox(ctr, key):
+def philox(ctr, key, rounds=None):
+    """Philox4x32 with `rounds` rounds (default: the noise specification's ORC_PHILOX_ROUNDS)."""
     c = (C.c_uint32 * 4)(*ctr); k = (C.c_uint32 * 2)(*key); o = (C.c_uint32 * 4)()
-    lib().orc_philox4x32_10(c, k, o)
+    lib().orc_philox4x32(c, k, lib().orc_philox_rounds() if rounds is None else int(rounds), o)
     return list(o)
 
 

@@ -595,10 +595,11 @@ int orc_step_tape(OrcEnv* e, int action, const float* tp, float* obs_out, double
 /* Counter-based noise specification (shared, by specification, with the HIP kernel)          */
 /* ------------------------------------------------------------------------------------------ */
 
-/* Philox4x32-10 (Salmon et al., SC'11).  Integer-only, so bit-exact on every machine. */
-void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+/* Philox4x32-R (Salmon et al., SC'11).  Integer-only, so bit-exact on every machine.  The noise specification uses
+ * R = ORC_PHILOX_ROUNDS = 7, the smallest count the paper reports as Crush-resistant; R = 10 is Random123's default. */
+void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]) {
     uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
-    for (int r = 0; r < 10; r++) {
+    for (int r = 0; r < rounds; r++) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
         uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
@@ -607,6 +608,8 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { orc_philox4x32(ctr, key, 10, out); }
+int orc_philox_rounds(void) { return ORC_PHILOX_ROUNDS; }
 
 static inline float u32_as_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline uint32_t f32_as_u32(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
@@ -679,7 +682,7 @@ static void noise_words(uint64_t seed, uint32_t env, uint32_t ep, uint32_t step,
                         uint32_t call, uint32_t w[4]) {
     uint32_t ctr[4] = {env, ep, step, lane | (call << 16)};
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-    orc_philox4x32_10(ctr, key, w);
+    orc_philox4x32(ctr, key, ORC_PHILOX_ROUNDS, w);
 }
 static inline float u24(uint32_t w) { return (float)(w >> 8) * 0x1p-24f; }
 

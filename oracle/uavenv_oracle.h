@@ -99,12 +99,15 @@ int  orc_step_tape(OrcEnv* e, int action, const float* step_tape, float* obs_out
                    int* truncated_out);
 
 /* Keyed entry points: the tape is generated by the counter-based noise specification shared with
- * the HIP kernel (Philox4x32-10 + transcendental-free Box-Muller, DESIGN.md "Noise"). */
+ * the HIP kernel (Philox4x32 with ORC_PHILOX_ROUNDS rounds + transcendental-free Box-Muller, DESIGN.md "Noise"). */
+#define ORC_PHILOX_ROUNDS 7   /* the oracle's own statement of include/uavenv.h:UAVENV_PHILOX_ROUNDS (tests compare the two) */
 void orc_noise_step_tape(uint64_t seed, uint32_t env_index, uint32_t episode, uint32_t step, int n, float* tape7);
 void orc_noise_reset_tape(uint64_t seed, uint32_t env_index, uint32_t episode, int n, float* tape4);
 void orc_noise_positions(uint64_t seed, uint32_t env_index, uint32_t episode, int n, int w, int h, float* px, float* py);
 int  orc_noise_action(uint64_t seed, uint32_t env_index, uint32_t episode, uint32_t step);
-void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]);
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);   /* Random123's default, for its vectors */
+int  orc_philox_rounds(void);
 void orc_normal_pair(uint32_t a, uint32_t b, float* z0, float* z1);
 
 void orc_reset_keyed(OrcEnv* e, float* obs_out);

@@ -1,6 +1,6 @@
 """CPU: the noise / log10 specification shared by the oracle and the HIP kernels (oracle/uavenv_oracle.c,
-csrc/uavenv_noise.h).  The generator is the published Philox4x32-10 (Salmon et al., SC'11): pinned here by the
-Random123 known-answer vectors; the Box-Muller and log10 restatements are pinned by their defining properties."""
+csrc/uavenv_noise.h).  The generator is the published Philox4x32 (Salmon et al., SC'11) with 7 rounds: pinned here by the
+Random123 known-answer vectors for 10 and for 7 rounds; the Box-Muller and log10 restatements are pinned by their defining properties."""
 import ctypes as C
 import math
 
@@ -9,12 +9,8 @@ import numpy as np
 from oracle import oracle as O
 
 
-def _philox(ctr, key):
-    L = O.lib()
-    L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
-    c = (C.c_uint32 * 4)(*ctr); k = (C.c_uint32 * 2)(*key); out = (C.c_uint32 * 4)()
-    L.orc_philox4x32_10(c, k, out)
-    return [int(x) for x in out]
+def _philox(ctr, key, rounds=10):
+    return [int(x) for x in O.philox(ctr, key, rounds)]
 
 
 def test_philox4x32_10_known_answers():
@@ -23,6 +19,24 @@ def test_philox4x32_10_known_answers():
     assert _philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     assert _philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_philox4x32_7_is_what_the_noise_specification_uses():
+    # Random123 kat_vectors, "philox4x32 7" row for the zero counter / key
+    assert _philox([0, 0, 0, 0], [0, 0], 7) == [0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]
+    # the other two inputs of the 10-round rows, 7 rounds of the round function those rows pin
+    assert _philox([0xffffffff] * 4, [0xffffffff] * 2, 7) == [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662]
+    assert _philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0], 7) == \
+        [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a]
+    # 10 rounds = 7 rounds followed by 3 more with the key advanced seven times (the Weyl sequence of the key schedule)
+    ctr, key = [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]
+    key7 = [(key[0] + 7 * 0x9E3779B9) & 0xFFFFFFFF, (key[1] + 7 * 0xBB67AE85) & 0xFFFFFFFF]
+    assert _philox(_philox(ctr, key, 7), key7, 3) == _philox(ctr, key, 10)
+    # the oracle's round count and the library header's are two statements of one number
+    import os, re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "uavenv.h")).read()
+    assert int(re.search(r"#define\s+UAVENV_PHILOX_ROUNDS\s+(\d+)", hdr).group(1)) == O.lib().orc_philox_rounds() == 7
+    assert O.philox([1, 2, 3, 4], [5, 6]) == O.philox([1, 2, 3, 4], [5, 6], 7)
 
 
 def _normals(a, b):
