@@ -129,24 +129,14 @@ __device__ __forceinline__ float readlane(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-// kZeroFill: lanes a masked DPP step leaves out may see 0 (sum) -- otherwise they must see their own value (max / min)
-struct OpSum { static constexpr bool kZeroFill = true; template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return a + b; } };
-struct OpMax { static constexpr bool kZeroFill = false; template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return b > a ? b : a; } };
-struct OpMin { static constexpr bool kZeroFill = false; template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return b < a ? b : a; } };
+struct OpSum { template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return a + b; } };
+struct OpMax { template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return b > a ? b : a; } };
+struct OpMin { template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return b < a ? b : a; } };
 
-// DPP row broadcasts (gfx9): row_bcast15 hands lane 15 of every row to the NEXT row, row_bcast31 lane 31 to rows 2 and 3; the
-// row mask restricts which rows take it (the others keep `old`).
+// DPP row broadcasts (gfx9): row_bcast15 hands lane 15 of every row to the NEXT row, row_bcast31 lane 31 to rows 2 and 3.  Rows
+// without a source read 0 (bound_ctrl): whatever they compute is never used -- only lane 63 is read, and its chain
+// row 0 -> row 1, row 2 -> row 3, row 1 -> row 3 has a valid source at every step.
 constexpr int kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
-template <int CTRL, int ROWS, bool kZeroFill> __device__ __forceinline__ float dpp_rows(float v) {
-    const int x = __float_as_int(v);
-    return __int_as_float(__builtin_amdgcn_update_dpp(kZeroFill ? 0 : x, x, CTRL, ROWS, 0xF, false));
-}
-template <int CTRL, int ROWS, bool kZeroFill> __device__ __forceinline__ double dpp_rows(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(kZeroFill ? 0 : lo, lo, CTRL, ROWS, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(kZeroFill ? 0 : hi, hi, CTRL, ROWS, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
 
 // all-lanes reduction over a lane group: 4 DPP steps inside each 16-lane row, then rows are
 // combined with one bpermute level (G = 32) or through SGPRs with v_readlane (G = 64: the group is
@@ -160,8 +150,8 @@ template <int G, typename T, typename Op> __device__ __forceinline__ T greduce(T
     if (G == 64) {
         // rows r0..r3 -> (r0 op r1) in row 1, (r2 op r3) in row 3 -> ((r2 op r3) op (r0 op r1)) in row 3: the same tree as
         // op(op(r0, r1), op(r2, r3)) (the operations commute exactly), two DPP steps and one lane read instead of four reads
-        v = op(v, dpp_rows<kDppRowBcast15, 0xA, Op::kZeroFill>(v));
-        v = op(v, dpp_rows<kDppRowBcast31, 0xC, Op::kZeroFill>(v));
+        v = op(v, dpp<kDppRowBcast15>(v));
+        v = op(v, dpp<kDppRowBcast31>(v));
         v = readlane(v, 63);
     }
     return v;
