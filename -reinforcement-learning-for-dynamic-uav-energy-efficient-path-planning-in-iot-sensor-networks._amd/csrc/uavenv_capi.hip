@@ -116,6 +116,11 @@ extern "C" int uavenv_create(const UavEnvConfig* cfg, int32_t num_envs, uint32_t
     e->cfg = *cfg;
     e->num_envs = num_envs; e->env_index_base = env_index_base; e->device = device;
     e->G = cfg->num_sensors <= 16 ? 16 : (cfg->num_sensors <= 32 ? 32 : 64);
+    {   // tuning knob: a wider lane group than the sensor count needs (UAVENV_LANE_GROUP = 32 or 64)
+        const char* lg = getenv("UAVENV_LANE_GROUP");
+        const int want = lg ? atoi(lg) : 0;
+        if ((want == 32 || want == 64) && want > e->G) e->G = want;
+    }
     const int per_block = kBlockThreads / e->G;
     e->padded_envs = ((num_envs + per_block - 1) / per_block) * per_block;
     derive_consts(e->cfg, e->consts);
