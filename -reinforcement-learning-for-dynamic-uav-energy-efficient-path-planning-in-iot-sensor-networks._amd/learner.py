@@ -24,6 +24,12 @@ reference:
     SB3's predict() flips ONE coin for the whole vector of environments; with thousands of environments that is an
     artefact, so every environment flips its own (shared_exploration_coin=True restores SB3's behaviour).
 
+Launch-bound loops are replayed as HIP graphs (`use_graphs`, single process): one vector step of acting -- Q-network forward,
+epsilon-greedy choice, environment step into the ring slot, frame stack, target copy -- is ~15 launches of a few
+microseconds of GPU work each behind ~270 us of Python, and a gradient step ~150 launches behind ~2 ms; captured once per
+ring slot (the slot's pointers are baked into the launches) and once for the update, a vector step of the reference
+configuration costs what its kernels cost.  The eager paths stay (several ranks, tests of the arithmetic).
+
 Everything stays on the GPU: the step kernel writes observations and (action, reward, done, terminal ticket) straight
 into the TransitionRing, the frame stack for acting is the uavenv_frame_stack kernel, sampled batches gather their
 frame stacks from the ring (each frame stored once instead of 2 x n_stack times, dqn.py:1085's budget).  With
@@ -126,7 +132,7 @@ class DQNLearner:
                  learning_starts=25_000, exploration_fraction=0.25, exploration_final_eps=0.03, exploration_initial_eps=1.0,
                  target_update_interval=5_000, train_freq=4, gradient_steps=1, net_arch=(512, 512, 256), n_stack=4,
                  total_timesteps=3_000_000, max_grad_norm=10.0, extractor="mlp", shared_exploration_coin=False, seed=0,
-                 chunk_len=None, reward_scale=1.0):
+                 chunk_len=None, reward_scale=1.0, use_graphs=None):
         """reward_scale (not an SB3 / reference option; default 1.0 = theirs): the environment's rewards reach 1e4-1e5 per
         step (+5000 per new sensor, 100 x bytes x urgency), which a smooth-L1 loss follows at one unit of gradient per
         sample -- the reference spends 750 k gradient steps on it.  Short runs (the tests) scale the reward in the loss."""
@@ -145,7 +151,13 @@ class DQNLearner:
         torch.manual_seed(seed)                                    # same seed on every rank: identical initial weights
         self.q = QNetwork(self.D, self.k, net_arch, extractor).to(self.dev)
         self.q_target = copy.deepcopy(self.q).requires_grad_(False)
-        self.opt = torch.optim.Adam(self.q.parameters(), lr=self.lr_schedule(1.0))
+        # (capturable + a tensor learning rate: the update can be replayed as a graph; eager steps use the same optimiser)
+        on_gpu = self.dev.type == "cuda"
+        self.opt = torch.optim.Adam(self.q.parameters(), lr=torch.tensor(self.lr_schedule(1.0), device=self.dev) if on_gpu
+                                    else self.lr_schedule(1.0), capturable=on_gpu)
+        self.use_graphs = (on_gpu and self.world == 1) if use_graphs is None else bool(use_graphs)
+        assert not (self.use_graphs and self.world > 1), "graph replay is single-process (the chunk collectives are issued from the host)"
+        self._act_graphs, self._train_graph = None, None
         self.gen = torch.Generator(device=self.dev).manual_seed(seed * 7919 + 13 + self.rank)
         # replay: buffer_size transitions = buffer_size // n_envs vector slots (SB3 ReplayBuffer), in chunks (one terminal
         # section and, across ranks, one collective per chunk); one chunk is always being recycled, hence the extra one
@@ -186,11 +198,91 @@ class DQNLearner:
             coin = torch.rand(self.E, device=self.dev, generator=self.gen)
         return torch.where(coin < epsilon, rnd, greedy)
 
+    # ---- graph replay of the two launch-bound loops ------------------------------------------------------
+    _GRAPH_SLOT_LIMIT = 1024            # one graph per ring slot: rings longer than this stay eager
+
+    def _set_lr(self, lr):
+        for g in self.opt.param_groups:
+            if torch.is_tensor(g["lr"]):
+                g["lr"].fill_(lr)
+            else:
+                g["lr"] = lr
+
+    def _after_vector_step(self):
+        self.num_timesteps += self.n_envs_total
+        self.n_calls += 1
+
+    def _capture_act_graphs(self):
+        """One graph per ring slot: act on the stacked observation, step the environments into that slot, push the frame
+        stack, copy the target network when it is due every step.  All graphs share one memory pool (they never overlap)."""
+        ring, E = self.ring, self.E
+        self._g_eps = torch.zeros((), device=self.dev)
+        self._g_tp = [p for p in self.q_target.parameters()] + [b for b in self.q_target.buffers()]
+        self._g_sp = [p.detach() for p in self.q.parameters()] + [b for b in self.q.buffers()]
+        pool = torch.cuda.graph_pool_handle()
+        graphs = [None] * ring.capacity
+        torch.cuda.synchronize(self.dev)
+        for slot in range(ring.capacity):
+            g = torch.cuda.CUDAGraph()
+            g.register_generator_state(self.gen)
+            with torch.cuda.graph(g, pool=pool), torch.no_grad():
+                ring._point_env(slot)
+                greedy = self.q(self.fs.stacked).argmax(1).to(torch.int32)
+                rnd = torch.randint(0, 5, (E,), device=self.dev, dtype=torch.int32, generator=self.gen)
+                coin = torch.rand(1 if self.shared_coin else E, device=self.dev, generator=self.gen)
+                actions = torch.where(coin < self._g_eps, rnd, greedy)
+                o, _, d = self.env.step(actions, obs_out=ring.local_obs_slot(slot))
+                self.fs.step(o, d, None)
+                if self.target_every == 1:
+                    torch._foreach_copy_(self._g_tp, self._g_sp)
+            graphs[slot] = g
+        ring._point_env()                # capturing executed nothing
+        self._act_graphs = graphs
+
+    def _capture_train_graph(self):
+        """One gradient step -- sample, TD loss, backward, clip, Adam -- as a graph.  Captured after eager updates have run
+        (optimizer state and library workspaces exist); the ring's sampling window and the learning rate are device scalars
+        refreshed before each replay."""
+        self._g_win = (torch.zeros((), dtype=torch.int64, device=self.dev), torch.zeros((), dtype=torch.int64, device=self.dev))
+        self._g_loss = torch.zeros((), device=self.dev)
+        self._g_index = torch.zeros(4, self.batch_size, dtype=torch.int64, device=self.dev)    # the last replay's draw (tests)
+        n, oldest = self.ring.window_state()
+        self._g_win[0].fill_(n); self._g_win[1].fill_(oldest)
+        params = list(self.q.parameters())
+        torch.cuda.synchronize(self.dev)
+        g = torch.cuda.CUDAGraph()
+        g.register_generator_state(self.gen)
+        with torch.cuda.graph(g):
+            batch = self.ring.sample_stacked(self.batch_size, self.k, generator=self.gen, window=self._g_win)
+            loss = td_loss(self.q, self.q_target, batch, self.gamma, self.reward_scale)
+            self.opt.zero_grad(set_to_none=True)
+            loss.backward()
+            nn.utils.clip_grad_norm_(params, self.max_grad_norm)
+            self.opt.step()
+            self._g_loss.copy_(loss.detach())
+            self._g_index.copy_(torch.stack(batch["index"]))
+        self._train_graph = g
+
+    def _graphs_usable(self):
+        return (self.use_graphs and self.dev.type == "cuda" and self.world == 1 and self.ring.capacity <= self._GRAPH_SLOT_LIMIT
+                and not self.ring.exchange)
+
     def collect(self, vector_steps):
         """SB3 collect_rollouts: `vector_steps` steps of every environment into the replay ring."""
         if self._stacked is None:
             self._start()
         for _ in range(vector_steps):
+            if self._act_graphs is None and self.n_calls >= 3 and self._graphs_usable():  # (libraries are warm after 3 eager steps)
+                self._capture_act_graphs()
+            if self._act_graphs is not None:
+                self._g_eps.fill_(self.exploration_rate())
+                self._act_graphs[self.ring.head].replay()
+                self.ring._advance(1)
+                self.ring._point_env()
+                self._after_vector_step()
+                if self.target_every != 1 and self.n_calls % self.target_every == 0:
+                    self.q_target.load_state_dict(self.q.state_dict())
+                continue
             actions = self.act(self._stacked, self.exploration_rate())
             o, _, d = self.env.step(actions, obs_out=self.ring.local_obs_slot())
             self.ring.commit()
@@ -202,11 +294,20 @@ class DQNLearner:
 
     # ---- learning -------------------------------------------------------------------------------------
     def train(self, gradient_steps=None):
-        lr = self.lr_schedule(self.progress_remaining())
-        for g in self.opt.param_groups:
-            g["lr"] = lr
+        self._set_lr(self.lr_schedule(self.progress_remaining()))
+        steps = self.gradient_steps if gradient_steps is None else gradient_steps
+        if self._graphs_usable() and self._train_graph is None and self.n_updates >= 3:
+            self._capture_train_graph()
+        if self._train_graph is not None:
+            n, oldest = self.ring.window_state()
+            self._g_win[0].fill_(n); self._g_win[1].fill_(oldest)
+            for _ in range(steps):
+                self._train_graph.replay()
+                self.n_updates += 1
+            self.last_loss = self._g_loss
+            return self._g_loss
         loss = None
-        for _ in range(self.gradient_steps if gradient_steps is None else gradient_steps):
+        for _ in range(steps):
             batch = self.ring.sample_stacked(self.batch_size, self.k, generator=self.gen)
             loss = td_loss(self.q, self.q_target, batch, self.gamma, self.reward_scale)
             self.opt.zero_grad(set_to_none=True)
@@ -218,8 +319,11 @@ class DQNLearner:
             nn.utils.clip_grad_norm_(self.q.parameters(), self.max_grad_norm)
             self.opt.step()
             self.n_updates += 1
-        self.last_loss = loss
-        return loss
+        # (detached: a loss that keeps its autograd graph keeps the parameters' AccumulateGrad nodes alive, and those remember
+        # the stream they were created on -- a later backward inside a graph capture would run them on that other stream,
+        # which ends the capture with a segmentation fault in the HIP runtime)
+        self.last_loss = None if loss is None else loss.detach()
+        return self.last_loss
 
     def learn(self, total_timesteps=None, callback=None):
         """SB3 OffPolicyAlgorithm.learn: rollouts of `train_freq` vector steps, each followed -- once `learning_starts`

@@ -249,7 +249,23 @@ class TransitionRing:
         chunked ring -- those of the head chunk, whose other-rank parts have not been gathered yet."""
         return self.size - (self.head % self.L if (self.exchange and self.L > 1) else 0)
 
-    def _draw(self, batch_size, generator):
+    def window_state(self):
+        """(n, oldest): the number of sampleable slots and the ring position of the oldest one -- the two host integers a
+        draw depends on.  `_draw(..., window=(n_dev, oldest_dev))` takes them as 0-d int64 device tensors instead, which
+        makes a sampling step replayable as a captured graph (the caller refreshes the two tensors before each replay)."""
+        n = self.sampleable()
+        assert self.size - n >= 0
+        return n, (self.head - self.size) % self.capacity
+
+    def _draw(self, batch_size, generator, window=None):
+        if window is not None:
+            n_dev, oldest_dev = window
+            # j uniform on 0 .. n-2 (the transition out of the newest sampleable slot has no successor yet)
+            u = torch.rand(batch_size, generator=generator, device=self.device, dtype=torch.float64)
+            j = torch.minimum((u * (n_dev - 1).to(torch.float64)).long(), n_dev - 2)
+            r = torch.randint(0, self.world, (batch_size,), generator=generator, device=self.device)
+            e = torch.randint(0, self.E, (batch_size,), generator=generator, device=self.device)
+            return j, (oldest_dev + j) % self.capacity, r, e
         n = self.sampleable()
         skip = self.size - n                       # committed but not yet visible slots right behind the head
         oldest = (self.head - self.size) % self.capacity
@@ -282,15 +298,19 @@ class TransitionRing:
         action, reward, done, last, valid = self._next_frame(slot, r, e)
         return dict(obs=self.obs_at(slot, r, e), action=action, reward=reward, done=done, next_obs=last, valid=valid)
 
-    def sample_stacked(self, batch_size, n_stack, generator=None):
+    def sample_stacked(self, batch_size, n_stack, generator=None, window=None):
         """Like sample(), but observations are frame stacks of `n_stack` frames gathered from the ring on the
         fly (SB3 VecFrameStack layout: [oldest | ... | newest], frames from before the episode start zeroed),
         so the replay stores each frame ONCE instead of n_stack times (dqn.py:1085 budgets 2 x 612 floats per
         transition for the stacked copies)."""
         assert self.sampleable() >= 2
         self.drain()
-        k = int(n_stack)
-        j, slot, r, e = self._draw(batch_size, generator)
+        return self.stacked_batch_at(*self._draw(batch_size, generator, window), n_stack)
+
+    def stacked_batch_at(self, j, slot, r, e, n_stack):
+        """The stacked transitions at drawn positions: j = age rank inside the sampling window (0 = oldest), slot = ring slot,
+        r = rank, e = environment (int64 tensors [B]).  The result carries them back as `index` (tests replay a draw)."""
+        k, batch_size = int(n_stack), int(slot.numel())
         back = torch.arange(k - 1, -1, -1, device=self.device)                      # k-1 ... 0 (oldest first)
         fs = (slot.unsqueeze(1) - back.unsqueeze(0)) % self.capacity                # [B, k] frame slots
         in_ring = (j.unsqueeze(1) - back.unsqueeze(0)) >= 0                         # frame older than the ring start?
@@ -305,4 +325,4 @@ class TransitionRing:
         # next stack = [frames 1..k-1 | newest]; after an auto-reset the real next state is the terminal observation
         next_obs = torch.cat([frames[:, 1:].reshape(batch_size, (k - 1) * self.D), last], 1)
         return dict(obs=frames.reshape(batch_size, k * self.D), action=action, reward=reward, done=done,
-                    next_obs=next_obs, valid=valid)
+                    next_obs=next_obs, valid=valid, index=(j, slot, r, e))

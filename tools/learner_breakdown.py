@@ -13,7 +13,7 @@ ext = os.environ.get("EXTRACTOR", "mlp")
 k = 4 if ext == "mlp" else 10
 env = U.BatchedUAVEnv(E, num_sensors=50, pad_sensors=50, grid_size=(500, 500), seed=0)
 hp = dict(REFERENCE_HYPERPARAMS, n_stack=k, total_timesteps=10**9)
-L = DQNLearner(env, extractor=ext, seed=0, **hp)
+L = DQNLearner(env, extractor=ext, seed=0, use_graphs=False, **hp)
 L.collect(64)
 torch.cuda.synchronize()
 
@@ -47,4 +47,18 @@ for _ in range(100):
     L.collect(L.train_freq); L.train()
 torch.cuda.synchronize()
 out["loop_us_per_vector_step"] = (time.perf_counter() - t0) / (L.n_calls - n0) * 1e6
+env2 = U.BatchedUAVEnv(E, num_sensors=50, pad_sensors=50, grid_size=(500, 500), seed=0)
+G = DQNLearner(env2, extractor=ext, seed=0, use_graphs=True, **dict(hp, learning_starts=0))
+for _ in range(12):
+    G.collect(G.train_freq); G.train()
+torch.cuda.synchronize()
+assert G._act_graphs is not None and G._train_graph is not None
+t0 = time.perf_counter(); n0 = G.n_calls
+for _ in range(200):
+    G.collect(G.train_freq); G.train()
+torch.cuda.synchronize()
+out["graph_loop_us_per_vector_step"] = (time.perf_counter() - t0) / (G.n_calls - n0) * 1e6
+out["graph_collect_1_us"] = timed(lambda: G.collect(1), 64)
+out["graph_train_1_us"] = timed(lambda: G.train(1), 30)
+out["graph_timesteps_per_s"] = E / (out["graph_loop_us_per_vector_step"] * 1e-6)
 print(json.dumps(out))
