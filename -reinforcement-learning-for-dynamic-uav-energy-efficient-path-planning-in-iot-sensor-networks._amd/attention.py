@@ -19,7 +19,7 @@ _NAMES = {
 }
 
 
-def pack_attention_weights(state_dict, n_stack, device):
+def pack_attention_weights(state_dict, n_stack, device, out=None):
     """Flatten the extractor's parameters into the block csrc/uavenv_attention.hip expects (weights transposed
     so that lane j of a wavefront reads consecutive addresses)."""
     def g(key):
@@ -35,7 +35,12 @@ def pack_attention_weights(state_dict, n_stack, device):
     parts = [uav_w.t(), g("uav_b"), g("ln1_g"), g("ln1_b"), sens_w[:, 0], sens_w[:, 1], sens_w[:, 2], g("sens_b"),
              wq.t(), in_b[:64], wk, in_b[64:128], wv.t(), in_b[128:], g("out_w").t(), g("out_b"), g("ln2_g"), g("ln2_b"),
              g("fuse_w").t(), g("fuse_b")]
-    flat = torch.cat([p.contiguous().reshape(-1) for p in parts]).contiguous()
+    pieces = [p.contiguous().reshape(-1) for p in parts]
+    if out is not None:                                   # refresh an existing block in place (same address: graph replays see it)
+        assert out.numel() == sum(p.numel() for p in pieces)
+        torch.cat(pieces, out=out)
+        return out
+    flat = torch.cat(pieces).contiguous()
     assert flat.numel() == N.lib().uavenv_attention_weight_floats(n_stack)
     return flat
 
@@ -46,6 +51,11 @@ class FusedAttentionFeatures:
         self.n_stack, self.device = int(n_stack), torch.device(device)
         self.weights = pack_attention_weights(sd, self.n_stack, self.device)
         self.L = N.lib()
+
+    def refresh(self, module_or_state_dict):
+        """Re-pack the (updated) parameters into the same weight block: ~25 small device copies, no host round trip."""
+        sd = module_or_state_dict.state_dict() if hasattr(module_or_state_dict, "state_dict") else module_or_state_dict
+        pack_attention_weights(sd, self.n_stack, self.device, out=self.weights)
 
     def __call__(self, obs):
         assert obs.is_cuda and obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[1] == self.n_stack * 153

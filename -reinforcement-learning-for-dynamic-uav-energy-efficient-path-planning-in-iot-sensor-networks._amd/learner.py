@@ -157,7 +157,7 @@ class DQNLearner:
                                     else self.lr_schedule(1.0), capturable=on_gpu)
         self.use_graphs = (on_gpu and self.world == 1) if use_graphs is None else bool(use_graphs)
         assert not (self.use_graphs and self.world > 1), "graph replay is single-process (the chunk collectives are issued from the host)"
-        self._act_graphs, self._train_graph = None, None
+        self._act_graphs, self._train_graph, self._fused = None, None, None
         self.gen = torch.Generator(device=self.dev).manual_seed(seed * 7919 + 13 + self.rank)
         # replay: buffer_size transitions = buffer_size // n_envs vector slots (SB3 ReplayBuffer), in chunks (one terminal
         # section and, across ranks, one collective per chunk); one chunk is always being recycled, hence the extra one
@@ -219,23 +219,44 @@ class DQNLearner:
         self._g_eps = torch.zeros((), device=self.dev)
         self._g_tp = [p for p in self.q_target.parameters()] + [b for b in self.q_target.buffers()]
         self._g_sp = [p.detach() for p in self.q.parameters()] + [b for b in self.q.buffers()]
+        # the attention extractor acts through the fused inference kernel (csrc/uavenv_attention.hip: one launch of ~50 us for
+        # 4096 stacked observations where the eager module spends ~860 us of GPU time); its weight block is re-packed after
+        # every update (train graph / eager train)
+        self._fused = None
+        if isinstance(self.q.features, AttentionFeatures) and self.D == 153:
+            from .attention import FusedAttentionFeatures
+            self._fused = FusedAttentionFeatures(self.q.features, self.k, self.dev)
+
+        def q_values(x):
+            return self.q.head(self._fused(x)) if self._fused is not None else self.q(x)
         pool = torch.cuda.graph_pool_handle()
         graphs = [None] * ring.capacity
         torch.cuda.synchronize(self.dev)
-        for slot in range(ring.capacity):
-            g = torch.cuda.CUDAGraph()
-            g.register_generator_state(self.gen)
-            with torch.cuda.graph(g, pool=pool), torch.no_grad():
-                ring._point_env(slot)
-                greedy = self.q(self.fs.stacked).argmax(1).to(torch.int32)
-                rnd = torch.randint(0, 5, (E,), device=self.dev, dtype=torch.int32, generator=self.gen)
-                coin = torch.rand(1 if self.shared_coin else E, device=self.dev, generator=self.gen)
-                actions = torch.where(coin < self._g_eps, rnd, greedy)
-                o, _, d = self.env.step(actions, obs_out=ring.local_obs_slot(slot))
-                self.fs.step(o, d, None)
-                if self.target_every == 1:
-                    torch._foreach_copy_(self._g_tp, self._g_sp)
-            graphs[slot] = g
+        # (raw capture_begin / capture_end on one side stream: the torch.cuda.graph context manager synchronises, collects
+        # garbage and empties the allocator cache around EVERY capture -- 20 ms each, a second for the 45 slots of the
+        # reference configuration)
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            for slot in range(ring.capacity):
+                g = torch.cuda.CUDAGraph()
+                g.register_generator_state(self.gen)
+                g.capture_begin(pool=pool)
+                try:
+                    ring._point_env(slot)
+                    greedy = q_values(self.fs.stacked).argmax(1).to(torch.int32)
+                    rnd = torch.randint(0, 5, (E,), device=self.dev, dtype=torch.int32, generator=self.gen)
+                    coin = torch.rand(1 if self.shared_coin else E, device=self.dev, generator=self.gen)
+                    actions = torch.where(coin < self._g_eps, rnd, greedy)
+                    o, _, d = self.env.step(actions, obs_out=ring.local_obs_slot(slot))
+                    self.fs.step(o, d, None)
+                    if self.target_every == 1:
+                        torch._foreach_copy_(self._g_tp, self._g_sp)
+                finally:
+                    g.capture_end()
+                graphs[slot] = g
+                del greedy, rnd, coin, actions, o, d
+        torch.cuda.current_stream(self.dev).wait_stream(side)
         ring._point_env()                # capturing executed nothing
         self._act_graphs = graphs
 
@@ -261,6 +282,8 @@ class DQNLearner:
             self.opt.step()
             self._g_loss.copy_(loss.detach())
             self._g_index.copy_(torch.stack(batch["index"]))
+            if self._fused is not None:
+                self._fused.refresh(self.q.features)
         self._train_graph = g
 
     def _graphs_usable(self):
@@ -323,6 +346,8 @@ class DQNLearner:
         # the stream they were created on -- a later backward inside a graph capture would run them on that other stream,
         # which ends the capture with a segmentation fault in the HIP runtime)
         self.last_loss = None if loss is None else loss.detach()
+        if self._fused is not None and loss is not None:
+            self._fused.refresh(self.q.features)
         return self.last_loss
 
     def learn(self, total_timesteps=None, callback=None):

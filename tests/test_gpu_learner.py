@@ -232,3 +232,24 @@ def test_graph_replay_of_the_update_is_the_eager_update_on_the_same_draw():
     for p, w in zip(L.q.parameters(), q0.parameters()):
         assert torch.allclose(p.detach(), w.detach(), rtol=1e-5, atol=1e-7)
     env.close()
+
+
+def test_attention_learner_acts_through_the_fused_kernel_with_current_weights():
+    """extractor="attention" under graph replay: acting uses the fused inference kernel, whose weight block is re-packed at the
+    end of every captured update -- after training, its features must be those of the (updated) PyTorch module."""
+    torch, U, LR = _mods()
+    env = U.BatchedUAVEnv(128, num_sensors=50, grid_size=(100, 100), max_steps=40, seed=2)
+    L = LR.DQNLearner(env, learning_rate=1e-3, buffer_size=128 * 24, batch_size=64, learning_starts=0, target_update_interval=128 * 3,
+                      train_freq=2, gradient_steps=1, net_arch=(64,), n_stack=4, total_timesteps=10**6, extractor="attention", seed=4,
+                      reward_scale=1e-4)
+    w0 = None
+    L.learn(total_timesteps=128 * 2 * 6)
+    assert L._fused is not None and L._act_graphs is not None and L._train_graph is not None
+    w0 = L._fused.weights.clone()
+    L.learn(total_timesteps=128 * 2 * 12)          # six more graph updates
+    assert not torch.equal(w0, L._fused.weights)
+    with torch.no_grad():
+        want = L.q.features(L.fs.stacked)
+    got = L._fused(L.fs.stacked)
+    assert torch.allclose(got, want, rtol=2e-4, atol=2e-5), float((got - want).abs().max())
+    env.close()
