@@ -70,11 +70,18 @@ def episode_stats_dtype():
     ])
 
 
+class UavRingLayout(C.Structure):
+    """include/uavenv.h:UavRingLayout (the transition ring of replay.py, for uavenv_ring_gather_stacked)."""
+    _fields_ = [("section", C.c_int64), ("num_chunks", C.c_int32), ("world", C.c_int32), ("slots_per_chunk", C.c_int32),
+                ("envs", C.c_int32), ("obs_dim", C.c_int32), ("terminal_rows", C.c_int32), ("block", C.c_int32),
+                ("obs_floats", C.c_int32), ("term_off", C.c_int32), ("count_off", C.c_int32)]
+
+
 EXPORTS = [
     "uavenv_abi_version", "uavenv_default_config", "uavenv_obs_dim", "uavenv_create", "uavenv_destroy",
     "uavenv_last_error", "uavenv_num_envs", "uavenv_lane_stride", "uavenv_env_obs_dim", "uavenv_set_env_params",
     "uavenv_set_positions", "uavenv_set_seed", "uavenv_set_grid_choices", "uavenv_set_noise_tape",
-    "uavenv_dump_noise", "uavenv_reset", "uavenv_step", "uavenv_step_random", "uavenv_step_random_n", "uavenv_step_policy", "uavenv_rollout", "uavenv_frame_stack", "uavenv_set_terminal_pool", "uavenv_set_aux_output", "uavenv_enable_terminal_snapshot", "uavenv_attention_weight_floats", "uavenv_attention_features", "uavenv_get_state",
+    "uavenv_dump_noise", "uavenv_reset", "uavenv_step", "uavenv_step_random", "uavenv_step_random_n", "uavenv_step_policy", "uavenv_rollout", "uavenv_frame_stack", "uavenv_ring_gather_stacked", "uavenv_set_terminal_pool", "uavenv_set_aux_output", "uavenv_enable_terminal_snapshot", "uavenv_attention_weight_floats", "uavenv_attention_features", "uavenv_get_state",
     "uavenv_set_state", "uavenv_state_bytes", "uavenv_reset_host", "uavenv_step_host", "uavenv_time_steps",
 ]
 
@@ -139,6 +146,7 @@ def _load(path):
         "uavenv_attention_weight_floats": (C.c_int, [i32]),
         "uavenv_attention_features": (C.c_int, [vp, vp, vp, i32, i32, vp]),
         "uavenv_frame_stack": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+        "uavenv_ring_gather_stacked": (C.c_int, [vp, C.POINTER(UavRingLayout), vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
         "uavenv_get_state": (C.c_int, [vp, i32, vp, C.c_size_t, i32, vp]),
         "uavenv_set_state": (C.c_int, [vp, i32, vp, C.c_size_t, i32, vp]),
         "uavenv_state_bytes": (C.c_size_t, [vp, i32]),

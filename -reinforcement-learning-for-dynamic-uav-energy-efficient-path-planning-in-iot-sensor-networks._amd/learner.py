@@ -154,7 +154,7 @@ class DQNLearner:
         # (capturable + a tensor learning rate: the update can be replayed as a graph; eager steps use the same optimiser)
         on_gpu = self.dev.type == "cuda"
         self.opt = torch.optim.Adam(self.q.parameters(), lr=torch.tensor(self.lr_schedule(1.0), device=self.dev) if on_gpu
-                                    else self.lr_schedule(1.0), capturable=on_gpu)
+                                    else self.lr_schedule(1.0), capturable=on_gpu, fused=on_gpu or None)
         self.use_graphs = (on_gpu and self.world == 1) if use_graphs is None else bool(use_graphs)
         assert not (self.use_graphs and self.world > 1), "graph replay is single-process (the chunk collectives are issued from the host)"
         self._act_graphs, self._train_graph, self._fused = None, None, None

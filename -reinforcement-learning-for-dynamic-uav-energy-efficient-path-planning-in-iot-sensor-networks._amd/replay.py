@@ -288,6 +288,40 @@ class TransitionRing:
         last = torch.where(have_term.unsqueeze(1), self._term4[c, r, row], self._obs5[c, r, j, e])
         return aux[:, 0].long(), aux[:, 1], done, last, ~done | have_term
 
+    def _stacked_batch_hip(self, j, slot, r, e, k, batch_size):
+        """stacked_batch_at in ONE launch (csrc/uavenv_replay.hip:uavenv_ring_gather_stacked) instead of ~40 indexing launches;
+        same bits (tests/test_gpu_api.py compares the two)."""
+        import ctypes as C
+        from . import _native as N
+        if self.__dict__.get("_layout") is None:
+            self._layout = N.UavRingLayout(section=self.section, num_chunks=self.n_chunks, world=self.world, slots_per_chunk=self.L,
+                                           envs=self.E, obs_dim=self.D, terminal_rows=self.T, block=self.block,
+                                           obs_floats=self.obs_floats, term_off=self.term_off, count_off=self.count_off)
+            self._glib = N.lib()
+        dev = self.device
+        idx = [t.to(torch.int64).contiguous() for t in (j, slot, r, e)]
+        obs = torch.empty(batch_size, k * self.D, dtype=torch.float32, device=dev)
+        nxt = torch.empty(batch_size, k * self.D, dtype=torch.float32, device=dev)
+        action = torch.empty(batch_size, dtype=torch.int64, device=dev)
+        reward = torch.empty(batch_size, dtype=torch.float32, device=dev)
+        done = torch.empty(batch_size, dtype=torch.bool, device=dev)
+        valid = torch.empty(batch_size, dtype=torch.bool, device=dev)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        rc = self._glib.uavenv_ring_gather_stacked(p(self.store), C.byref(self._layout), p(idx[0]), p(idx[1]), p(idx[2]), p(idx[3]),
+                                                   batch_size, k, p(obs), p(nxt), p(action), p(reward), p(done), p(valid),
+                                                   C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc:
+            raise RuntimeError(f"uavenv_ring_gather_stacked failed ({rc})")
+        return dict(obs=obs, action=action, reward=reward, done=done, next_obs=nxt, valid=valid, index=(j, slot, r, e))
+
+    def stacked_batch_at_torch(self, j, slot, r, e, n_stack):
+        """The PyTorch statement of stacked_batch_at (CPU rings; the reference the HIP gather is tested against)."""
+        try:
+            self.__dict__["_force_torch"] = True
+            return self.stacked_batch_at(j, slot, r, e, n_stack)
+        finally:
+            self.__dict__["_force_torch"] = False
+
     def sample(self, batch_size, generator=None):
         """Uniform sample of transitions (obs, action, reward, done, next_obs, valid) over all ranks' envs.
         Slot s holds the observation s_t together with (a, r, done) of the step that PRODUCED it, so the
@@ -311,6 +345,8 @@ class TransitionRing:
         """The stacked transitions at drawn positions: j = age rank inside the sampling window (0 = oldest), slot = ring slot,
         r = rank, e = environment (int64 tensors [B]).  The result carries them back as `index` (tests replay a draw)."""
         k, batch_size = int(n_stack), int(slot.numel())
+        if self.store.is_cuda and k <= 16 and not self.__dict__.get("_force_torch", False):
+            return self._stacked_batch_hip(j, slot, r, e, k, batch_size)
         back = torch.arange(k - 1, -1, -1, device=self.device)                      # k-1 ... 0 (oldest first)
         fs = (slot.unsqueeze(1) - back.unsqueeze(0)) % self.capacity                # [B, k] frame slots
         in_ring = (j.unsqueeze(1) - back.unsqueeze(0)) >= 0                         # frame older than the ring start?

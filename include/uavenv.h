@@ -281,6 +281,25 @@ int uavenv_enable_terminal_snapshot(UavEnv* env, int32_t enable);
 int uavenv_frame_stack(float* stacked_dev, const float* obs_dev, const uint8_t* done_dev, const float* terminal_obs_dev,
                        float* terminal_stacked_dev, int32_t num_envs, int32_t num_frames, int32_t obs_dim, void* stream);
 
+/* ---- replay sampling (the consumer of the transitions the step kernel writes: dqn.py:1083-1089 ReplayBuffer) -------- */
+/* The transition ring of replay.py: store[chunk][rank][ slots_per_chunk blocks | terminal rows | count ], all in floats;
+ * block = [ envs x obs_dim observations, padded to obs_floats | envs x 4 aux = (action, reward, done, ticket bits) ]. */
+typedef struct UavRingLayout {
+    int64_t section;            /* floats per (chunk, rank) part                                        */
+    int32_t num_chunks, world, slots_per_chunk, envs, obs_dim, terminal_rows;
+    int32_t block, obs_floats;  /* floats per block; offset of the aux rows inside a block              */
+    int32_t term_off, count_off;/* float offsets of the terminal rows / the int32 counter inside a part */
+} UavRingLayout;
+/* replaces: ReplayBuffer.sample + VecFrameStack's stacking for a drawn batch, in one launch.  For sample b with ring slot
+ * slot[b], rank[b], env[b] and age[b] (slots between the oldest sampleable slot and slot[b]): obs_out[b] = the num_frames
+ * frames ending at the slot (oldest first; frames from before the episode start or before the ring start zeroed),
+ * next_obs_out[b] = frames 1.. + the next observation (the terminal row after an auto-reset), action / reward / done of the
+ * step out of the slot, valid = 0 where the terminal row has been overwritten.  num_frames <= 16.  Needs no UavEnv handle. */
+int uavenv_ring_gather_stacked(const float* store_dev, const UavRingLayout* layout, const int64_t* age_dev, const int64_t* slot_dev,
+                               const int64_t* rank_dev, const int64_t* env_dev, int32_t batch, int32_t num_frames,
+                               float* obs_out_dev, float* next_obs_out_dev, int64_t* action_out_dev, float* reward_out_dev,
+                               uint8_t* done_out_dev, uint8_t* valid_out_dev, void* stream);
+
 /* ---- the consumer of the observation layout: UAVAttentionExtractor forward (dqn.py:548-650) ------------- */
 /* replaces: UAVAttentionExtractor.forward for inference, fused into one launch.  obs_dev float
  * [batch][n_stack*153] (the frame-stacked, 50-slot padded observation), weights_dev = the extractor's parameters

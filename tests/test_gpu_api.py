@@ -401,3 +401,34 @@ def test_vec_env_with_builtin_frame_stack():
         for i, row in terminal.items():
             assert np.array_equal(ia[i]["terminal_observation"], row)
     a.close(); b.close()
+
+
+def test_hip_ring_gather_equals_the_pytorch_statement():
+    """uavenv_ring_gather_stacked (one launch per sampled batch) against TransitionRing.stacked_batch_at_torch (the tensor
+    expressions it replaces), on a chunked ring that has wrapped around, with a terminal section too small for the episode-end
+    bursts (overwritten rows must come back as valid = False) and draws that reach before the ring start."""
+    torch, U, O = _mods()
+    E, k = 40, 5
+    env = U.BatchedUAVEnv(E, num_sensors=10, max_steps=7, seed=11)       # every environment ends an episode every 7 steps
+    D = env.obs_dim
+    ring = U.TransitionRing(24, E, D, env.device, chunk_len=6, terminal_rows=16); ring.attach(env)
+    obs = env.reset(); ring.local_obs_slot().copy_(obs)
+    z = torch.zeros(E, device=env.device); ring.commit(z, z, z)
+    for s in range(61):                                                    # 2.5 revolutions
+        env.step_random(obs_out=ring.local_obs_slot()); ring.commit()
+    n, oldest = ring.window_state()
+    g = torch.Generator(device=env.device).manual_seed(4)
+    B = 3000
+    j = torch.randint(0, n - 1, (B,), generator=g, device=env.device)
+    j[:40] = torch.arange(40, device=env.device) % 4                       # stacks that reach before the ring start
+    slot = (oldest + j) % ring.capacity
+    r = torch.zeros(B, dtype=torch.int64, device=env.device)
+    e = torch.randint(0, E, (B,), generator=g, device=env.device)
+    got = ring.stacked_batch_at(j, slot, r, e, k)
+    want = ring.stacked_batch_at_torch(j, slot, r, e, k)
+    for key in ("obs", "next_obs", "action", "reward", "done", "valid"):
+        assert got[key].dtype == want[key].dtype and got[key].shape == want[key].shape, key
+        assert torch.equal(got[key], want[key]), key
+    assert bool(got["done"].any()) and not bool(got["valid"].all()) and bool(got["valid"].any())
+    assert bool((got["obs"][:40, :D] == 0).all())                          # the frames from before the ring start are zero
+    env.close()
