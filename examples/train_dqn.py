@@ -50,14 +50,24 @@ def main():
     learner = DQNLearner(env, extractor=args.extractor, seed=args.seed, reward_scale=args.reward_scale, **hp)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    learner.learn()
+    half = {}
+
+    def mark(l):            # the second half of the run is free of one-time costs (library warm-up, graph captures)
+        if "t" not in half and l.num_timesteps >= args.timesteps // 2:
+            torch.cuda.synchronize()
+            half.update(t=time.perf_counter(), n=l.num_timesteps, calls=l.n_calls)
+    learner.learn(callback=mark)
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    dt = t1 - t0
     st = env.episode_stats()
     done_eps = st[st["valid"] == 1]
     out = {"envs": args.envs, "sensors": args.sensors, "n_stack": args.n_stack, "extractor": args.extractor,
            "timesteps": learner.num_timesteps, "vector_steps": learner.n_calls, "timesteps_per_s": learner.num_timesteps / dt,
            "ms_per_vector_step": dt / max(1, learner.n_calls) * 1e3, "gradient_steps": learner.n_updates,
+           "second_half_timesteps_per_s": (learner.num_timesteps - half["n"]) / (t1 - half["t"]) if "t" in half and t1 > half["t"] else None,
+           "second_half_ms_per_vector_step": (t1 - half["t"]) / max(1, learner.n_calls - half["calls"]) * 1e3 if "t" in half else None,
+           "graph_replay": learner._act_graphs is not None and learner._train_graph is not None,
            "last_loss": None if learner.last_loss is None else float(learner.last_loss.detach()),
            "learning_rate_now": learner.lr_schedule(learner.progress_remaining()), "epsilon_now": learner.exploration_rate(),
            "replay_slots": learner.ring.capacity, "replay_chunk": learner.ring.L,
