@@ -340,6 +340,12 @@ def main():
     run_steps(0, align=True)
     back_to_back_ms = env.time_steps(min(K, 1000))
     torch.cuda.synchronize(dev)
+    launch_source = f"HIP events on the launch stream around {ev_steps} steps of this run's launch path"
+    if exchange == "allgather":
+        # with the exchange the launch stream also waits for the chunk collectives (a chunk is not overwritten before its
+        # previous gather is done): events around the loop then time the exchange, not the kernel
+        kern_ms = back_to_back_ms
+        launch_source = "HIP events around back-to-back launches into one buffer (the launch path of this run waits for its collectives)"
 
     # Additional measurement for N > 1 (never `value`): the same K steps WITHOUT the exchange, every rank filling a ring of
     # its own.  The exchange replicates every observation on every GPU (2.6 MB per rank and step) and is bound by the
@@ -421,7 +427,7 @@ def main():
                      "kernel": "uav_step_kernel<64, true, 16, true> (lane group 64, lean, 16-wave workgroups, default-config literals)",
                      "algorithmic_bytes_per_launch": per_launch_bytes,
                      "algorithmic_bytes_per_env_step": B, "avg_launch_ms": kern_ms,
-                     "avg_launch_source": f"HIP events on the launch stream around {ev_steps} steps of this run's launch path",
+                     "avg_launch_source": launch_source,
                      "timed_region_event_ms_per_step": ev_ms / K, "back_to_back_ms": back_to_back_ms,
                      "note": "path is VALU/latency bound (Philox + float64 physics per sensor), not HBM bound: "
                              "see DESIGN.md"},
