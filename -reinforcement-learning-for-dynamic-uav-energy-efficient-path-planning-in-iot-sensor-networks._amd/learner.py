@@ -38,6 +38,7 @@ torch.distributed initialised, every rank steps its own shard of environments, t
 """
 import copy
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -132,7 +133,7 @@ class DQNLearner:
                  learning_starts=25_000, exploration_fraction=0.25, exploration_final_eps=0.03, exploration_initial_eps=1.0,
                  target_update_interval=5_000, train_freq=4, gradient_steps=1, net_arch=(512, 512, 256), n_stack=4,
                  total_timesteps=3_000_000, max_grad_norm=10.0, extractor="mlp", shared_exploration_coin=False, seed=0,
-                 chunk_len=None, reward_scale=1.0, use_graphs=None):
+                 chunk_len=None, reward_scale=1.0, use_graphs=None, tune_gemms=None):
         """reward_scale (not an SB3 / reference option; default 1.0 = theirs): the environment's rewards reach 1e4-1e5 per
         step (+5000 per new sensor, 100 x bytes x urgency), which a smooth-L1 loss follows at one unit of gradient per
         sample -- the reference spends 750 k gradient steps on it.  Short runs (the tests) scale the reward in the loss."""
@@ -158,6 +159,19 @@ class DQNLearner:
         self.use_graphs = (on_gpu and self.world == 1) if use_graphs is None else bool(use_graphs)
         assert not (self.use_graphs and self.world > 1), "graph replay is single-process (the chunk collectives are issued from the host)"
         self._act_graphs, self._train_graph, self._fused = None, None, None
+        # tune_gemms (default: with the graphs): PyTorch's TunableOp picks the GEMM kernel per shape by timing the candidates the
+        # first time a shape is seen (the eager steps before the captures).  The update is a dozen float32 GEMMs of batch 256
+        # whose default kernels leave most of the 256 CUs idle (14-29 us each): 599 -> 343 us per update.  It is a process-wide
+        # PyTorch switch; tuning is switched off again once both graphs exist (the chosen kernels stay in use).
+        self.tune_gemms = self.use_graphs if tune_gemms is None else bool(tune_gemms)
+        if self.tune_gemms and on_gpu:
+            import torch.cuda.tunable as tunable
+            tunable.enable(True)
+            tunable.tuning_enable(True)
+            try:
+                tunable.set_filename(os.devnull)          # keep the results in memory: no tunableop_results*.csv in the cwd
+            except Exception:
+                pass
         self.gen = torch.Generator(device=self.dev).manual_seed(seed * 7919 + 13 + self.rank)
         # replay: buffer_size transitions = buffer_size // n_envs vector slots (SB3 ReplayBuffer), in chunks (one terminal
         # section and, across ranks, one collective per chunk); one chunk is always being recycled, hence the extra one
@@ -285,6 +299,9 @@ class DQNLearner:
             if self._fused is not None:
                 self._fused.refresh(self.q.features)
         self._train_graph = g
+        if self.tune_gemms and self._act_graphs is not None:
+            import torch.cuda.tunable as tunable
+            tunable.tuning_enable(False)                  # every shape of the two loops has been seen
 
     def _graphs_usable(self):
         return (self.use_graphs and self.dev.type == "cuda" and self.world == 1 and self.ring.capacity <= self._GRAPH_SLOT_LIMIT
