@@ -159,11 +159,13 @@ class DQNLearner:
         self.use_graphs = (on_gpu and self.world == 1) if use_graphs is None else bool(use_graphs)
         assert not (self.use_graphs and self.world > 1), "graph replay is single-process (the chunk collectives are issued from the host)"
         self._act_graphs, self._train_graph, self._fused = None, None, None
-        # tune_gemms (default: with the graphs): PyTorch's TunableOp picks the GEMM kernel per shape by timing the candidates the
-        # first time a shape is seen (the eager steps before the captures).  The update is a dozen float32 GEMMs of batch 256
-        # whose default kernels leave most of the 256 CUs idle (14-29 us each): 599 -> 343 us per update.  It is a process-wide
-        # PyTorch switch; tuning is switched off again once both graphs exist (the chosen kernels stay in use).
-        self.tune_gemms = self.use_graphs if tune_gemms is None else bool(tune_gemms)
+        # tune_gemms (default off): PyTorch's TunableOp picks the GEMM kernel per shape by timing the candidates the first time a
+        # shape is seen (the eager steps before the captures).  The update is a dozen float32 GEMMs of batch 256 whose default
+        # kernels leave most of the 256 CUs idle (14-29 us each): 599 -> 348 us per update (1 491 -> 864 us with the attention
+        # extractor), 13.8 -> 17.6 M and 7.2 -> 9.9 M timesteps/s.  The tuning itself takes 3 s (13 s with the attention
+        # extractor) -- more than the reference's whole 3 M-timestep run lasts here -- hence opt-in, for long runs.  It is a
+        # process-wide PyTorch switch; tuning is switched off again once both graphs exist (the chosen kernels stay in use).
+        self.tune_gemms = False if tune_gemms is None else bool(tune_gemms)
         if self.tune_gemms and on_gpu:
             import torch.cuda.tunable as tunable
             tunable.enable(True)
