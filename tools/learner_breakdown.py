@@ -48,7 +48,8 @@ for _ in range(100):
 torch.cuda.synchronize()
 out["loop_us_per_vector_step"] = (time.perf_counter() - t0) / (L.n_calls - n0) * 1e6
 env2 = U.BatchedUAVEnv(E, num_sensors=50, pad_sensors=50, grid_size=(500, 500), seed=0)
-G = DQNLearner(env2, extractor=ext, seed=0, use_graphs=True, **dict(hp, learning_starts=0))
+G = DQNLearner(env2, extractor=ext, seed=0, use_graphs=True, tune_gemms=os.environ.get("TUNE_GEMMS") == "1", **dict(hp, learning_starts=0))
+out["tune_gemms"] = os.environ.get("TUNE_GEMMS") == "1"
 for _ in range(12):
     G.collect(G.train_freq); G.train()
 torch.cuda.synchronize()
