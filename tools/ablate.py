@@ -20,7 +20,7 @@ for name, flags in VARIANTS:
     lib = os.path.join(OUT, f"lib_{name}.so")
     procs.append((name, lib, subprocess.Popen(
         ["hipcc"] + HIPCC_FLAGS + flags +
-        ["-o", lib, os.path.join(PKG, "csrc", "uavenv_kernels.hip"), os.path.join(PKG, "csrc", "uavenv_capi.hip"), os.path.join(PKG, "csrc", "uavenv_attention.hip")])))
+        ["-o", lib, os.path.join(PKG, "csrc", "uavenv_kernels.hip"), os.path.join(PKG, "csrc", "uavenv_capi.hip"), os.path.join(PKG, "csrc", "uavenv_attention.hip"), os.path.join(PKG, "csrc", "uavenv_replay.hip")])))
 for name, lib, p in procs:
     assert p.wait() == 0, name
 child = r'''

@@ -19,7 +19,7 @@ LIB = os.path.join(ROOT, "gpurun_out", "libuavenv_hip_stamps.so")
 os.makedirs(os.path.dirname(LIB), exist_ok=True)
 subprocess.check_call(["hipcc"] + HIPCC_FLAGS + [
                        "-DUAVENV_STAMPS", "-o", LIB] + [os.path.join(PKG, "csrc", f) for f in
-                       ("uavenv_kernels.hip", "uavenv_capi.hip", "uavenv_attention.hip")])
+                       ("uavenv_kernels.hip", "uavenv_capi.hip", "uavenv_attention.hip", "uavenv_replay.hip")])
 import uavenv_amd  # noqa: E402
 from uavenv_amd import _native as N  # noqa: E402
 N.LIB_PATH = LIB
