@@ -314,14 +314,6 @@ class TransitionRing:
             raise RuntimeError(f"uavenv_ring_gather_stacked failed ({rc})")
         return dict(obs=obs, action=action, reward=reward, done=done, next_obs=nxt, valid=valid, index=(j, slot, r, e))
 
-    def stacked_batch_at_torch(self, j, slot, r, e, n_stack):
-        """The PyTorch statement of stacked_batch_at (CPU rings; the reference the HIP gather is tested against)."""
-        try:
-            self.__dict__["_force_torch"] = True
-            return self.stacked_batch_at(j, slot, r, e, n_stack)
-        finally:
-            self.__dict__["_force_torch"] = False
-
     def sample(self, batch_size, generator=None):
         """Uniform sample of transitions (obs, action, reward, done, next_obs, valid) over all ranks' envs.
         Slot s holds the observation s_t together with (a, r, done) of the step that PRODUCED it, so the
@@ -345,8 +337,13 @@ class TransitionRing:
         """The stacked transitions at drawn positions: j = age rank inside the sampling window (0 = oldest), slot = ring slot,
         r = rank, e = environment (int64 tensors [B]).  The result carries them back as `index` (tests replay a draw)."""
         k, batch_size = int(n_stack), int(slot.numel())
-        if self.store.is_cuda and k <= 16 and not self.__dict__.get("_force_torch", False):
+        if self.store.is_cuda and k <= 16:
             return self._stacked_batch_hip(j, slot, r, e, k, batch_size)
+        return self.stacked_batch_at_torch(j, slot, r, e, n_stack)
+
+    def stacked_batch_at_torch(self, j, slot, r, e, n_stack):
+        """stacked_batch_at as tensor expressions: what CPU rings run, and the statement the HIP gather is tested against."""
+        k, batch_size = int(n_stack), int(slot.numel())
         back = torch.arange(k - 1, -1, -1, device=self.device)                      # k-1 ... 0 (oldest first)
         fs = (slot.unsqueeze(1) - back.unsqueeze(0)) % self.capacity                # [B, k] frame slots
         in_ring = (j.unsqueeze(1) - back.unsqueeze(0)) >= 0                         # frame older than the ring start?
