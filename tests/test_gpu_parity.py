@@ -207,6 +207,21 @@ def test_keyed_rollout_matches_oracle(case):
     env.close()
 
 
+@pytest.mark.parametrize("width", ["32", "64"])
+def test_wider_lane_group_than_needed_matches_oracle(monkeypatch, width):
+    """UAVENV_LANE_GROUP (read by uavenv_create): 10 sensors in 32- and 64-lane groups, 20 sensors in 64 lanes -- the same
+    environments, stepped by the kernels of the wider group (for 64: one environment per wavefront, scalar record path)."""
+    torch, U, O = _mods()
+    monkeypatch.setenv("UAVENV_LANE_GROUP", width)
+    env = U.BatchedUAVEnv(8, num_sensors=10, seed=1)
+    assert env.lane_stride == int(width)
+    env.close()
+    test_keyed_rollout_matches_oracle(("n10_wide", 130, dict(num_sensors=10, max_steps=50, duty_cycle=100.0, grid_size=(90, 90)), 200, 0))
+    if width == "64":
+        test_keyed_rollout_matches_oracle(("n20_wide", 100, dict(num_sensors=20, max_battery=9.0, duty_cycle=80.0, grid_size=(150, 150)), 200, 0))
+        test_keyed_rollout_matches_oracle(("n20_default_consts_wide", 300, dict(num_sensors=20, max_steps=40), 90, 0))
+
+
 def test_given_actions_and_manual_reset_match_oracle():
     """auto_reset=False (single gymnasium.Env semantics): explicit actions, masked reset on truncation."""
     torch, U, O = _mods()
