@@ -310,7 +310,10 @@ int uavenv_attention_features(const float* obs_dev, const float* weights_dev, fl
                               int32_t n_stack, void* stream);
 
 /* ---- state access (checkpoint / parity / the attribute reads of SURVEY 1) -------------------- */
-/* Copies one whole field.  `bytes` must equal the field size; dst/src may be host or device. */
+/* Copies one whole field.  `bytes` must equal the field size; dst/src may be host or device.
+ * A state handed to uavenv_set_state must be one the library could have produced: 0 <= data_buffer <= max_buffer_size in every
+ * lane, INCLUDING the lanes beyond an environment's sensor count (the kernels leave those rows alone by arithmetic -- they add 0
+ * bytes and clamp with min / max -- not by masking them out; what uavenv_get_state returned always qualifies). */
 int uavenv_get_state(UavEnv* env, int32_t field, void* dst, size_t bytes, int32_t dst_on_device, void* stream);
 int uavenv_set_state(UavEnv* env, int32_t field, const void* src, size_t bytes, int32_t src_on_device, void* stream);
 size_t uavenv_state_bytes(const UavEnv* env, int32_t field);
