@@ -82,6 +82,37 @@ def test_transition_ring_single_rank_cpu():
     assert torch.all(b["next_obs"][~m][:, 0] == b["obs"][~m][:, 0] + 1)
 
 
+def test_transition_ring_draws_from_a_device_window():
+    """`_draw(..., window=(n, oldest))` (the form a captured graph replays: the two integers arrive as tensors) covers exactly the
+    positions the host-integer draw covers, and `stacked_batch_at` on such a draw equals the sampled batch."""
+    import torch
+    from uavenv_amd.replay import TransitionRing
+    E, D, k = 5, 4, 3
+    ring = TransitionRing(12, E, D, "cpu", chunk_len=4)
+    g0 = torch.Generator().manual_seed(3)
+    for s in range(30):                                            # wraps 2.5 times
+        ring.local_obs_slot().copy_(torch.randn(E, D, generator=g0))
+        done = (torch.rand(E, generator=g0) < 0.2).float()
+        ring.commit(torch.randint(0, 5, (E,), generator=g0), torch.randn(E, generator=g0), done,
+                    terminal_obs=torch.randn(E, D, generator=g0))
+    n, oldest = ring.window_state()
+    assert n == ring.sampleable() and oldest == (ring.head - ring.size) % ring.capacity
+    win = (torch.tensor(n), torch.tensor(oldest))
+    g = torch.Generator().manual_seed(7)
+    j, slot, r, e = ring._draw(5000, g, win)
+    assert int(j.min()) == 0 and int(j.max()) == n - 2 and len(torch.unique(j)) == n - 1      # every position, none beyond
+    assert torch.equal(slot, (oldest + j) % ring.capacity) and int(r.max()) == 0 and set(e.tolist()) == set(range(E))
+    counts = torch.bincount(j, minlength=n - 1).float()
+    assert float(counts.std() / counts.mean()) < 0.15                                          # uniform over the window
+    g = torch.Generator().manual_seed(7)
+    b = ring.sample_stacked(64, k, generator=g, window=win)
+    jj, ss, rr, ee = b["index"]
+    again = ring.stacked_batch_at(jj, ss, rr, ee, k)
+    for key in ("obs", "next_obs", "action", "reward", "done", "valid"):
+        assert torch.equal(b[key], again[key]), key
+    assert b["obs"].shape == (64, k * D) and b["next_obs"].shape == (64, k * D)
+
+
 def test_transition_ring_detects_overwritten_terminal_rows():
     """episode ends come in bursts.  A chunk whose terminal section is too small for its episode ends must
     flag the overwritten rows (valid = False), never return another environment's observation."""
