@@ -78,6 +78,12 @@ class OrcEnv(C.Structure):
     ]
 
 
+class OrcEpisodeStats(C.Structure):
+    _fields_ = [(k, _D) for k in ("total_generated", "total_collected", "total_lost", "battery_remaining", "ndr",
+                                  "fairness_std", "jains_index", "data_efficiency", "bytes_per_wh")] + \
+               [(k, C.c_int32) for k in ("grid_w", "grid_h", "num_sensors", "rated", "length", "first_full_coverage_step")]
+
+
 _lib = None
 
 
@@ -125,6 +131,9 @@ def lib():
         L.orc_trace_keyed.restype = C.c_long
         L.orc_rssi_deterministic.argtypes = [C.POINTER(OrcConfig), C.c_float, C.c_float, C.c_float, C.c_float]
         L.orc_rssi_deterministic.restype = _D
+        L.orc_episode_stats.argtypes = [C.POINTER(OrcEnv), C.POINTER(OrcEpisodeStats)]
+        L.orc_noise_words.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                      C.POINTER(C.c_uint32)]
         assert C.sizeof(OrcConfig) > 0
         _lib = L
     return _lib
@@ -213,6 +222,10 @@ class OracleEnv:
             raise ValueError(f"Invalid action: {action}")
         return obs, r.value, bool(tr.value)
 
+    def episode_stats(self):
+        """dqn.py:316-331 `last_episode_stats` of the episode the current state ends (call before the next reset)."""
+        return episode_stats_of(self.e)
+
     def next_random_action(self):
         return self.L.orc_noise_action(self.cfg.seed, self.e.env_index, self.e.episode, self.e.current_step + 1)
 
@@ -232,7 +245,22 @@ class OracleEnv:
             capture_triggers=np.int32(e.capture_triggers), boundary_hits=np.int32(e.boundary_hits),
             edge_steps=np.int32(e.edge_steps), last_bytes=np.float64(e.last_step_bytes),
             episode=np.uint32(e.episode), grid_w=np.int32(e.grid_w), grid_h=np.int32(e.grid_h),
+            start_x=np.float32(e.start_x), start_y=np.float32(e.start_y),
         )
+
+
+def episode_stats_of(e):
+    st = OrcEpisodeStats()
+    lib().orc_episode_stats(C.byref(e), C.byref(st))
+    d = {k: getattr(st, k) for k, _ in OrcEpisodeStats._fields_}
+    d["grid_size"] = (d.pop("grid_w"), d.pop("grid_h"))
+    return d
+
+
+def noise_words(seed, env_index, episode, step, lane, call):
+    o = (C.c_uint32 * 4)()
+    lib().orc_noise_words(int(seed), env_index & 0xFFFFFFFF, episode & 0xFFFFFFFF, step, lane, call, o)
+    return list(o)
 
 
 def philox(ctr, key, rounds=None):

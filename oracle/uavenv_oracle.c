@@ -517,6 +517,36 @@ static double jains_index(const OrcEnv* e, int* count_out) {
     return 1.0;
 }
 
+/* dqn.py:305-331 last_episode_stats: python sum() = sequential float64 adds, np.std = sqrt(mean(|x - mean(x)|^2)) with
+ * numpy's pairwise sums, `_jains` over the percentage rates (:446-451). */
+void orc_episode_stats(const OrcEnv* e, OrcEpisodeStats* o) {
+    const OrcConfig* c = &e->cfg;
+    int n = e->n, cnt = 0, visited = 0;
+    double rates[ORC_MAX_SENSORS], dv[ORC_MAX_SENSORS];
+    double tg = 0.0, tc = 0.0, tl = 0.0;
+    for (int i = 0; i < n; i++) {
+        if (e->gen[i] > 0) rates[cnt++] = e->tx[i] / e->gen[i] * 100;              /* :308-312 */
+        tg += e->gen[i]; tc += e->tx[i]; tl += e->lost[i];                          /* :313-314, :319 */
+        visited += e->visited[i];
+    }
+    double battery_used = c->max_battery - e->battery;                             /* :315 */
+    o->total_generated = tg; o->total_collected = tc; o->total_lost = tl;
+    o->battery_remaining = e->battery;
+    o->ndr = (double)visited / n * 100;                                            /* :321 */
+    o->fairness_std = 0.0;
+    if (cnt > 0) {                                                                 /* :322 np.std */
+        double mean = np_sum_f64(rates, cnt) / cnt;
+        for (int i = 0; i < cnt; i++) { double d = rates[i] - mean; dv[i] = d * d; }
+        o->fairness_std = sqrt(np_sum_f64(dv, cnt) / cnt);
+    }
+    o->jains_index = jains_index(e, NULL);                                         /* :323 */
+    o->grid_w = e->grid_w; o->grid_h = e->grid_h; o->num_sensors = n; o->rated = cnt;
+    o->data_efficiency = tg > 0 ? tc / tg * 100 : 0.0;                             /* :326-327 */
+    o->bytes_per_wh = battery_used > 0 ? tc / battery_used : 0.0;                  /* :328-329 */
+    o->length = e->current_step;
+    o->first_full_coverage_step = e->first_full_coverage_step;
+}
+
 /* uav_env.py:429-488 step (+ dqn.py:415-444 DomainRandEnv.step when shaping flags are set) */
 int orc_step_tape(OrcEnv* e, int action, const float* tp, float* obs_out, double* reward_out,
                   int* truncated_out) {
@@ -685,6 +715,9 @@ static void noise_words(uint64_t seed, uint32_t env, uint32_t ep, uint32_t step,
     orc_philox4x32(ctr, key, ORC_PHILOX_ROUNDS, w);
 }
 static inline float u24(uint32_t w) { return (float)(w >> 8) * 0x1p-24f; }
+void orc_noise_words(uint64_t seed, uint32_t env, uint32_t ep, uint32_t step, uint32_t lane, uint32_t call, uint32_t w[4]) {
+    noise_words(seed, env, ep, step, lane, call, w);
+}
 
 void orc_noise_step_tape(uint64_t seed, uint32_t env, uint32_t ep, uint32_t step, int n, float* tp) {
     for (int i = 0; i < n; i++) {

@@ -126,6 +126,20 @@ long orc_trace_keyed(const OrcConfig* c, int num_envs, uint32_t base, int steps,
                      int auto_reset, float* obs_out, double* rew_out, uint8_t* done_out, float* term_out,
                      int32_t* actions_out, float* reset_obs_out, OrcEnv* final_envs);
 
+/* dqn.py:305-331: what DomainRandEnv.reset snapshots into `last_episode_stats` from the state the finished episode left
+ * behind (call it BEFORE the reset that opens the next episode).  `rated` = number of sensors with generated data
+ * (len(sensor_rates)); fairness_std = np.std(sensor_rates) (numpy's two-pass form over pairwise sums), 0 when none. */
+typedef struct OrcEpisodeStats {
+    double total_generated, total_collected, total_lost, battery_remaining, ndr, fairness_std, jains_index,
+           data_efficiency, bytes_per_wh;
+    int32_t grid_w, grid_h, num_sensors, rated, length, first_full_coverage_step;
+} OrcEpisodeStats;
+void orc_episode_stats(const OrcEnv* e, OrcEpisodeStats* out);
+
+/* the four Philox words of one call of the noise specification (counter layout: DESIGN.md "Noise") */
+void orc_noise_words(uint64_t seed, uint32_t env_index, uint32_t episode, uint32_t step, uint32_t lane, uint32_t call,
+                     uint32_t out[4]);
+
 /* Scalar known-answer helpers. */
 float  orc_log10_f32(float d);
 double orc_rssi_deterministic(const OrcConfig* c, float ux, float uy, float sx, float sy);

@@ -113,3 +113,71 @@ def test_oracle_policies_replay_reference_agents(name):
             episode += 1
             assert np.array_equal(env.reset_tape(T.reset_tape(seed, 0, episode, n)), fx["reset_obs"][episode])
     assert len(G.policy_fixture_names()) >= 5
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SURVEY rows a17 + f4: the REAL DomainRandEnv (tests/golden/make_golden_domainrand.py), keyed noise
+# ---------------------------------------------------------------------------------------------------------------
+def test_domainrand_fixtures_present():
+    names = G.domainrand_fixture_names()
+    assert len(names) >= 10
+    finished = sum(int(G.load(n)["truncated"].sum()) for n in names)
+    assert finished >= 20                      # every fixture holds >= 2 finished episodes
+
+
+def check_domainrand_stats(got, row, keys, rtol=1e-12):
+    """`got`: dict with the dqn.py:316-331 keys; `row`: the fixture's values in `keys` order."""
+    want = dict(zip(keys, row))
+    for k in ("total_generated", "total_collected", "total_lost", "battery_remaining", "ndr", "fairness_std", "jains_index",
+              "data_efficiency", "bytes_per_wh"):
+        assert abs(got[k] - want[k]) <= rtol * max(1.0, abs(want[k])), (k, got[k], want[k])
+    assert tuple(got["grid_size"]) == (int(want["grid_w"]), int(want["grid_h"]))
+    assert got["num_sensors"] == int(want["num_sensors"])
+
+
+@pytest.mark.parametrize("name", G.domainrand_fixture_names())
+def test_oracle_replays_real_domainrand(name):
+    """reset (grid draw, inherited SF, fresh layout, far start, padded obs), step (shaping + Jain bonus), truncation and
+    `last_episode_stats` of the real class, from nothing but (seed, env_index, actions)."""
+    fx = G.load(name)
+    meta = fx["meta"]
+    env = O.OracleEnv(O.default_config(**G.domainrand_overrides(meta)), meta["env_index"])
+    ep = 0
+
+    def open_episode():
+        obs = env.reset_keyed()
+        st = env.state()
+        assert np.array_equal(obs, fx["ep_reset_obs"][ep]), (name, ep)
+        assert (st["grid_w"], st["grid_h"]) == tuple(fx["ep_grid"][ep])
+        assert (st["start_x"], st["start_y"]) == tuple(fx["ep_start"][ep]) == (st["uav_x"], st["uav_y"])
+        assert np.array_equal(np.stack([st["pos_x"], st["pos_y"]], -1), fx["ep_pos"][ep])
+
+    open_episode()
+    for s, a in enumerate(fx["actions"]):
+        obs, r, tr = env.step_keyed(int(a))
+        assert np.array_equal(obs, fx["obs"][s]), (name, s)
+        assert abs(r - fx["reward"][s]) <= 1e-12 * max(1.0, abs(fx["reward"][s])), (name, s, r, fx["reward"][s])
+        assert tr == bool(fx["truncated"][s]), (name, s)
+        assert np.array_equal(env.state()["sf"], fx["sf"][s]), (name, s)
+        if tr:
+            got = env.episode_stats()
+            check_domainrand_stats(got, fx["ep_stats"][ep], meta["stat_keys"])
+            ep += 1
+            open_episode()
+    assert ep == len(fx["ep_stats"]) >= 2
+    st = env.state()
+    for k in ("sf", "visited", "data_collected", "uav_x", "uav_y", "step", "capture_triggers", "boundary_hits", "edge_steps"):
+        assert np.array_equal(st[k], fx["final_" + k]), k
+    for k in ("buffer", "gen", "tx", "lost", "battery", "total_reward", "total_collected", "last_bytes"):
+        assert np.allclose(st[k], fx["final_" + k], rtol=1e-12, atol=1e-9), k
+
+
+def test_oracle_episode_stats_without_rates():
+    """dqn.py:322-329 guards: no sensor generated data -> fairness_std 0.0, `_jains([])` = 1.0, data_efficiency 0.0; and
+    bytes_per_wh 0.0 when no battery was used."""
+    cfg = O.default_config(num_sensors=4, grid_size=(100, 100), data_generation_rate=0.0, flags=1)
+    env = O.OracleEnv(cfg, 0)
+    env.reset_keyed()
+    st = env.episode_stats()
+    assert st["rated"] == 0 and st["fairness_std"] == 0.0 and st["jains_index"] == 1.0
+    assert st["data_efficiency"] == 0.0 and st["bytes_per_wh"] == 0.0 and st["ndr"] == 0.0
