@@ -80,7 +80,7 @@ class UavRingLayout(C.Structure):
 EXPORTS = [
     "uavenv_abi_version", "uavenv_default_config", "uavenv_obs_dim", "uavenv_create", "uavenv_destroy",
     "uavenv_last_error", "uavenv_num_envs", "uavenv_lane_stride", "uavenv_env_obs_dim", "uavenv_set_env_params",
-    "uavenv_set_positions", "uavenv_set_seed", "uavenv_set_grid_choices", "uavenv_set_noise_tape",
+    "uavenv_set_positions", "uavenv_set_seed", "uavenv_get_config", "uavenv_set_config", "uavenv_set_grid_choices", "uavenv_set_noise_tape",
     "uavenv_dump_noise", "uavenv_reset", "uavenv_step", "uavenv_step_random", "uavenv_step_random_n", "uavenv_step_policy", "uavenv_rollout", "uavenv_frame_stack", "uavenv_ring_gather_stacked", "uavenv_set_terminal_pool", "uavenv_set_aux_output", "uavenv_enable_terminal_snapshot", "uavenv_attention_weight_floats", "uavenv_attention_features", "uavenv_get_state",
     "uavenv_set_state", "uavenv_state_bytes", "uavenv_reset_host", "uavenv_step_host", "uavenv_time_steps",
 ]
@@ -131,6 +131,8 @@ def _load(path):
         "uavenv_set_env_params": (C.c_int, [vp, vp, vp, vp]),
         "uavenv_set_positions": (C.c_int, [vp, vp, vp]),
         "uavenv_set_seed": (C.c_int, [vp, u64]),
+        "uavenv_get_config": (C.c_int, [vp, cfgp]),
+        "uavenv_set_config": (C.c_int, [vp, cfgp]),
         "uavenv_set_grid_choices": (C.c_int, [vp, i32, vp, vp]),
         "uavenv_set_noise_tape": (C.c_int, [vp, vp, vp]),
         "uavenv_dump_noise": (C.c_int, [vp, vp, vp, vp]),

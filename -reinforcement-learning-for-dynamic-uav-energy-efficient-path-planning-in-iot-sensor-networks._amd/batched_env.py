@@ -94,6 +94,9 @@ class BatchedUAVEnv:
         self.reward = torch.zeros(E, dtype=torch.float64, device=dev)
         self.actions_taken = torch.zeros(E, dtype=torch.int32, device=dev)
         self._tapes = (None, None)
+        # counts the calls that change what a step launch carries BY VALUE and a captured HIP graph therefore keeps in its
+        # old form (include/uavenv.h:uavenv_set_seed): holders of captured graphs compare it (replay.py, learner.py)
+        self.launch_epoch = 0
         if sensor_positions is not None:
             self.set_positions(sensor_positions)
 
@@ -138,6 +141,23 @@ class BatchedUAVEnv:
 
     def seed(self, seed):
         N.check(self.L.uavenv_set_seed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF), self._h)
+        self.launch_epoch += 1
+
+    def set_config(self, **overrides):
+        """Change constants of the LIVE environments (uavenv_set_config): the reference's kwargs and/or UavEnvConfig field names,
+        e.g. `set_config(shadowing_std_db=8.0)` for what sim_to_real_sweep.py:113-117 does to every sensor.  Takes effect
+        with the next step; captured graphs must be captured again (launch_epoch)."""
+        cfg = N.UavEnvConfig()
+        N.check(self.L.uavenv_get_config(self._h, C.byref(cfg)), self._h)
+        over = {}
+        for k, v in overrides.items():
+            if k in _REF_IGNORED:
+                continue
+            over[_REF_KWARGS.get(k, k)] = v
+        N.apply_overrides(cfg, over)
+        N.check(self.L.uavenv_set_config(self._h, C.byref(cfg)), self._h)
+        self.cfg = cfg
+        self.launch_epoch += 1
 
     def set_grid_choices(self, grids):
         w = (C.c_int32 * 8)(*[int(g[0]) for g in grids]); h = (C.c_int32 * 8)(*[int(g[1]) for g in grids])
@@ -151,6 +171,7 @@ class BatchedUAVEnv:
                 assert tuple(t.shape) == (self.num_envs, slots, self.lane_stride), tuple(t.shape)
         self._tapes = (step_tape, reset_tape)        # keep alive
         N.check(self.L.uavenv_set_noise_tape(self._h, self._p(step_tape), self._p(reset_tape)), self._h)
+        self.launch_epoch += 1
 
     def set_terminal_pool(self, pool=None, counter=None, index_out=None):
         """pool float32 cuda [rows, D]; counter int32/uint32 cuda [1]; index_out int32 cuda [E] (or all None)."""
@@ -178,6 +199,7 @@ class BatchedUAVEnv:
         (uavenv_enable_terminal_snapshot): read it with `terminal_snapshot(indices)`."""
         N.check(self.L.uavenv_enable_terminal_snapshot(self._h, 1 if enable else 0), self._h)
         self._term_snapshot = bool(enable)
+        self.launch_epoch += 1
 
     def terminal_snapshot(self, indices):
         """(records [k] structured, sensors [k, 3, lane_stride] float64 = buffer / generated / transmitted) of the last

@@ -51,7 +51,7 @@ def generate_default_consts(verbose=False):
     """csrc/uavenv_default_consts.inc: the default configuration's derived constants as exact hex-float literals, printed by
     a host program built from the SAME uavenv_derive.h the C ABI uses (the kernels' literal specialisation includes it).
     The file is committed (the GPU box's dev tools compile the kernels too); it is rewritten only when its content changes."""
-    gen = os.path.join(CSRC, "_gen_default_consts")
+    gen = os.path.join(CSRC, f"_gen_default_consts.{os.getpid()}")          # per process: ranks may get here together
     subprocess.check_call([hipcc(), "-O1", "-std=c++17", "-o", gen, os.path.join(CSRC, "gen_default_consts.cpp")],
                           stderr=None if verbose else subprocess.DEVNULL)
     try:
@@ -59,21 +59,42 @@ def generate_default_consts(verbose=False):
     finally:
         os.remove(gen)
     if not os.path.exists(GENERATED) or open(GENERATED).read() != text:
-        with open(GENERATED, "w") as f:
+        tmp = f"{GENERATED}.{os.getpid()}.tmp"
+        with open(tmp, "w") as f:
             f.write(text)
+        os.replace(tmp, GENERATED)
     return text
 
 
 def build(force=False, verbose=False):
+    """Several processes may call this at once (every rank of a torchrun job loads the library): one of them builds under
+    an exclusive file lock, into a temporary file that is renamed into place, and the others find a fresh library when
+    they get the lock -- nobody can load a half-written one."""
     if not force and not stale():
         return LIB
-    generate_default_consts(verbose)
-    cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    with open(STAMP, "w") as f:
-        f.write(source_hash() + "\n")
+    import fcntl
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not stale():                  # another process built it while this one waited
+                return LIB
+            generate_default_consts(verbose)
+            tmp = f"{LIB}.{os.getpid()}.tmp"
+            cmd = [hipcc()] + FLAGS + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+            if verbose:
+                print(" ".join(cmd).replace(tmp, LIB))
+            try:
+                subprocess.check_call(cmd)
+                os.replace(tmp, LIB)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+            stamp_tmp = f"{STAMP}.{os.getpid()}.tmp"
+            with open(stamp_tmp, "w") as f:
+                f.write(source_hash() + "\n")
+            os.replace(stamp_tmp, STAMP)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 

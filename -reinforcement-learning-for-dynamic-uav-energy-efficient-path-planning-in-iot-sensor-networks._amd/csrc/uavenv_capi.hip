@@ -230,6 +230,32 @@ extern "C" int uavenv_set_seed(UavEnv* e, uint64_t seed) {
     return UAVENV_OK;
 }
 
+extern "C" int uavenv_get_config(const UavEnv* e, UavEnvConfig* out) {
+    if (!e || !out) return UAVENV_E_INVALID;
+    *out = e->cfg;
+    return UAVENV_OK;
+}
+
+// Re-derive the constants of a LIVE handle (sim_to_real_sweep.py:109-117 sets shadowing_std_db / path-loss parameters on
+// the sensors of an existing environment).  What sizes the buffers and the observation rows must stay as created.
+extern "C" int uavenv_set_config(UavEnv* e, const UavEnvConfig* cfg) {
+    if (!e || !cfg) return UAVENV_E_INVALID;
+    if (cfg->struct_size != sizeof(UavEnvConfig)) return fail(e, UAVENV_E_INVALID, "UavEnvConfig.struct_size mismatch (ABI)");
+    if (cfg->num_sensors != e->cfg.num_sensors || cfg->pad_sensors != e->cfg.pad_sensors ||
+        (cfg->include_sensor_positions != 0) != (e->cfg.include_sensor_positions != 0))
+        return fail(e, UAVENV_E_INVALID, "num_sensors, pad_sensors and include_sensor_positions are fixed at uavenv_create");
+    if (!(cfg->max_buffer_size > 0) || !(cfg->max_battery > 0)) return fail(e, UAVENV_E_INVALID, "max_buffer_size and max_battery must be positive");
+    if (cfg->num_grid_choices < 0 || cfg->num_grid_choices > 8) return fail(e, UAVENV_E_INVALID, "num_grid_choices must be in 0..8");
+    const bool reseeded = cfg->seed != e->cfg.seed;
+    e->cfg = *cfg;
+    derive_consts(e->cfg, e->consts);
+    e->default_consts = e->allow_literals && consts_are_default(e->consts);
+    int rc = upload_consts(e);                              // synchronises the device
+    if (rc) return rc;
+    if (reseeded) HIP_TRY(e, hipMemset(e->hints, 0, 2 * (size_t)e->padded_envs * sizeof(uint32_t)));
+    return UAVENV_OK;
+}
+
 extern "C" int uavenv_set_grid_choices(UavEnv* e, int32_t count, const int32_t* w, const int32_t* h) {
     if (!e || count < 0 || count > 8 || (count > 0 && (!w || !h))) return UAVENV_E_INVALID;
     e->cfg.num_grid_choices = count; e->consts.n_grid_choices = count;

@@ -416,7 +416,9 @@ template <typename T> __device__ __forceinline__ void store_wt(T* q, T v, bool w
 }
 typedef float __attribute__((ext_vector_type(3))) f32x3;
 __device__ __forceinline__ void store3_wt(float* q, float a, float b, float c, bool wt) {
-    if (wt) { f32x3 v = {a, b, c}; asm volatile("global_store_dwordx3 %0, %1, off sc1" :: "v"(q), "v"(v) : "memory"); }
+    // (s_nop 0: a VALU write to the data registers of a > 64-bit VMEM store needs one wait state after the store issues, and
+    //  the hazard recogniser does not look inside inline assembly -- the register allocator reuses these registers at once)
+    if (wt) { f32x3 v = {a, b, c}; asm volatile("global_store_dwordx3 %0, %1, off sc1\n\ts_nop 0" :: "v"(q), "v"(v) : "memory"); }
     else { struct __attribute__((packed, aligned(4))) P3 { float a, b, c; }; P3 w{a, b, c}; *reinterpret_cast<P3*>(q) = w; }
 }
 

@@ -105,7 +105,24 @@ class SensorView:
     rssi_threshold = property(lambda s: float(s._env._cfg.rssi_threshold))
     duty_cycle = property(lambda s: float(s._env._cfg.duty_cycle))
     duty_cycle_probability = property(lambda s: float(s._env._cfg.duty_cycle) / 100.0)
-    shadowing_std_db = property(lambda s: float(s._env._cfg.shadowing_std_db))
+
+    # The channel constants live once per environment, not per sensor: writing one through ANY sensor changes it for all of
+    # them -- which is what the reference's sweeps do anyway (`for s in env.sensors: s.shadowing_std_db = sigma`,
+    # sim_to_real_sweep.py:113-117).
+    def _cfg_property(field):
+        def get(s):
+            return float(getattr(s._env._cfg, field))
+
+        def set_(s, value):
+            s._env._set_config(**{field: float(value)})
+        return property(get, set_)
+
+    shadowing_std_db = _cfg_property("shadowing_std_db")
+    transmit_power_dbm = _cfg_property("tx_power_dbm")
+    noise_floor_dbm = _cfg_property("noise_floor_dbm")
+    adr_lambda = _cfg_property("adr_lambda")
+    path_loss_exponent = property(lambda s: 3.8, lambda s, v: None)     # stored by IoTSensor, read by nothing (iot_sensors.py:72)
+    del _cfg_property
 
     @property
     def avg_rssi(self):
@@ -176,6 +193,10 @@ class UAVEnvironment(_Base):
         self._rec = None
         self._snap = None
         self._act = torch.zeros(1, dtype=torch.int32, device=self._benv.device)
+
+    def _set_config(self, **overrides):
+        self._benv.set_config(**overrides)
+        self._cfg = self._benv.cfg
 
     # ---- cached device state --------------------------------------------------------------------
     def _invalidate(self):

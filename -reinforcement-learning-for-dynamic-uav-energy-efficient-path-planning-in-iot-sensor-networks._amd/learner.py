@@ -275,6 +275,7 @@ class DQNLearner:
         torch.cuda.current_stream(self.dev).wait_stream(side)
         ring._point_env()                # capturing executed nothing
         self._act_graphs = graphs
+        self._act_epoch = self.env.launch_epoch
 
     def _capture_train_graph(self):
         """One gradient step -- sample, TD loss, backward, clip, Adam -- as a graph.  Captured after eager updates have run
@@ -314,6 +315,8 @@ class DQNLearner:
         if self._stacked is None:
             self._start()
         for _ in range(vector_steps):
+            if self._act_graphs is not None and self._act_epoch != self.env.launch_epoch:
+                self._act_graphs = None          # env.seed() etc. since the capture: the launches carry stale arguments
             if self._act_graphs is None and self.n_calls >= 3 and self._graphs_usable():  # (libraries are warm after 3 eager steps)
                 self._capture_act_graphs()
             if self._act_graphs is not None:

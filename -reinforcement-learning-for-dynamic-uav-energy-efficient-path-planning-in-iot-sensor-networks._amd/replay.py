@@ -35,6 +35,11 @@ def _pad4(n):
     return (int(n) + 3) & ~3
 
 
+class _ChunkGraphs(list):
+    """The graphs capture_chunks returns + the environment's launch epoch at capture time."""
+    epoch = 0
+
+
 class TransitionRing:
     def __init__(self, capacity, envs_per_rank, obs_dim, device, world_size=1, rank=0, group=None, terminal_rows=None,
                  chunk_len=1, always_exchange=False):
@@ -204,7 +209,8 @@ class TransitionRing:
         assert self.device.type == "cuda" and self._env is not None and self.head % self.L == 0
         self.drain()
         torch.cuda.synchronize(self.device)
-        head0, graphs = self.head, [None] * self.n_chunks
+        head0, graphs = self.head, _ChunkGraphs([None] * self.n_chunks)
+        graphs.epoch = self._env.launch_epoch
         for k in range(self.n_chunks):
             c = (head0 // self.L + k) % self.n_chunks
             g = torch.cuda.CUDAGraph()
@@ -232,6 +238,9 @@ class TransitionRing:
         """Replay the graph of the chunk at the head and commit its L slots."""
         c = self.head // self.L
         assert self.head % self.L == 0
+        if getattr(graphs, "epoch", self._env.launch_epoch) != self._env.launch_epoch:
+            raise RuntimeError("these chunk graphs were captured before env.seed() / set_noise_tape() / enable_terminal_snapshot(): "
+                               "their launches still carry the old values -- capture_chunks() again")
         self.wait_chunk(c)            # its previous gather (a full revolution ago) must be done before it is overwritten;
         graphs[c].replay()            # the gather of the chunk just before this one keeps running on the side stream
         self._advance(self.L)

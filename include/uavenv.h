@@ -179,8 +179,22 @@ int uavenv_env_obs_dim(const UavEnv* env);
 int uavenv_set_env_params(UavEnv* env, const int32_t* grid_w, const int32_t* grid_h, const int32_t* num_sensors);
 /* replaces: the sensor_positions kwarg (uav_env.py:269); host float [E][stride] */
 int uavenv_set_positions(UavEnv* env, const float* pos_x, const float* pos_y);
-/* replaces: reset(seed=...) / VecEnv.seed(): re-keys all randomness */
+/* replaces: reset(seed=...) / VecEnv.seed(): re-keys all randomness.
+ * The seed travels to the step kernels as a launch ARGUMENT (it is preloaded into SGPRs with the wave launch), and a captured
+ * HIP graph keeps the arguments it was captured with: graphs of step / rollout launches captured before this call go on drawing
+ * with the OLD seed and must be captured again.  The same holds for everything else a launch takes by value: the tape pointers
+ * (uavenv_set_noise_tape), the terminal pool, the aux output and the terminal snapshot.  (uavenv_amd: BatchedUAVEnv.launch_epoch
+ * counts these calls; TransitionRing.replay_chunk and DQNLearner refuse / re-capture graphs of an older epoch.) */
 int uavenv_set_seed(UavEnv* env, uint64_t seed);
+/* replaces: attribute writes on a LIVE environment's sensors / UAV / reward function, e.g. `s.shadowing_std_db = sigma` for
+ * every sensor in agents/dqn/dqn_evaluation_results/sim_to_real_sweep.py:109-117: read the handle's configuration, change
+ * fields, hand it back.  The constants are re-derived and take effect with the next launch (the call synchronises the
+ * device).  num_sensors, pad_sensors and include_sensor_positions (buffer and observation sizes) must stay as created
+ * (UAVENV_E_INVALID otherwise).  The state is left alone: per-environment grids / sensor counts (uavenv_set_env_params)
+ * are kept, a smaller max_buffer_size is the caller's to reconcile with the buffers (see uavenv_set_state).  Like
+ * uavenv_set_seed it changes launch ARGUMENTS (the literal-constants kernel variant is chosen per launch): re-capture graphs. */
+int uavenv_get_config(const UavEnv* env, UavEnvConfig* out);
+int uavenv_set_config(UavEnv* env, const UavEnvConfig* cfg);
 /* replaces: DomainRandEnv.set_curriculum_stage (dqn.py:258-277): grid list sampled at each reset */
 int uavenv_set_grid_choices(UavEnv* env, int32_t count, const int32_t* w, const int32_t* h);
 
