@@ -103,9 +103,30 @@ def test_config3_learner_4096x50_graph_path_equals_eager_and_oracle(extractor, n
     acts = rg._aux5[..., 0].flatten()[: (steps + 1) * E]
     assert int(torch.bincount(acts.long(), minlength=5).min()) > steps * E // 8              # all five actions, evenly
     assert torch.equal(Lg.fs.stacked, Le.fs.stacked)
-    for p, q in zip(Lg.q.parameters(), Le.q.parameters()):                                    # the same ten updates
-        assert torch.allclose(p, q, rtol=1e-3, atol=1e-5), float((p - q).abs().max())
     assert all(not torch.equal(p, p0) for p, p0 in zip(Lg.q.parameters(), init))
+    # (the two learners draw their batches differently -- integer draws vs the graph's device-side window arithmetic -- so
+    #  their weights are not comparable; instead: one more captured update against the same update done by hand, eagerly, on
+    #  the transitions the replay drew)
+    import copy
+    q0, t0 = copy.deepcopy(Lg.q), copy.deepcopy(Lg.q_target)
+    opt0 = torch.optim.Adam(q0.parameters(), lr=torch.tensor(0.0, device=Lg.dev), capturable=True)
+    opt0.load_state_dict(copy.deepcopy(Lg.opt.state_dict()))
+    Lg.train(1)
+    torch.cuda.synchronize()
+    j, slot, r, e = [Lg._g_index[i] for i in range(4)]
+    assert int(e.max()) < E and len(torch.unique(e)) > 200 and int(j.max()) <= Lg.ring.sampleable() - 2
+    batch = Lg.ring.stacked_batch_at(j, slot, r, e, Lg.k)
+    assert batch["obs"].shape == (256, n_stack * 153) and bool(batch["valid"].all())
+    for g in opt0.param_groups:
+        g["lr"].fill_(Lg.lr_schedule(Lg.progress_remaining()))
+    loss = LR.td_loss(q0, t0, batch, Lg.gamma, Lg.reward_scale)
+    opt0.zero_grad(set_to_none=True)
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(q0.parameters(), Lg.max_grad_norm)
+    opt0.step()
+    assert float(loss.detach()) == pytest.approx(float(Lg.last_loss), rel=1e-4)
+    for p, w in zip(Lg.q.parameters(), q0.parameters()):
+        assert torch.allclose(p.detach(), w.detach(), rtol=1e-4, atol=1e-6), float((p.detach() - w.detach()).abs().max())
     _oracle_replay_of_ring(O, rg, over, [0, 1, 63, 64, 1000, 2047, 2048, 4095], steps)
     if extractor == "attention":
         assert Lg._fused is not None
