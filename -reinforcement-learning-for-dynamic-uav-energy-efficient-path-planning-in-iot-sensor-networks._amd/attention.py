@@ -1,6 +1,6 @@
 """Fused inference forward of the reference's UAVAttentionExtractor (agents/dqn/dqn.py:548-650) on the
 frame-stacked observations of this environment: one HIP launch instead of ~15 eager PyTorch launches
-(csrc/uavenv_attention.hip).  Training still uses the PyTorch module; this is the acting path."""
+(csrc/uavenv_attention.hip: 16 samples per workgroup, the shared-weight projections on the f32 MFMA).  Training still uses the PyTorch module; this is the acting path."""
 import ctypes as C
 
 import torch
@@ -19,9 +19,18 @@ _NAMES = {
 }
 
 
+def _frag(wt):
+    """[K, N] (the TRANSPOSED weight: K inputs, N outputs) -> MFMA fragment order [N / 16 tiles][64 lanes][K / 4]: lane
+    l = (k-group g = l >> 4, column c = l & 15) of tile nt holds wt[g * K/4 + t][16 * nt + c] for t = 0 .. K/4 - 1
+    (csrc/uavenv_attention.hip: mfma_tile)."""
+    K, n = wt.shape
+    return wt.reshape(4, K // 4, n // 16, 16).permute(2, 0, 3, 1).reshape(-1)
+
+
 def pack_attention_weights(state_dict, n_stack, device, out=None):
-    """Flatten the extractor's parameters into the block csrc/uavenv_attention.hip expects (weights transposed
-    so that lane j of a wavefront reads consecutive addresses)."""
+    """Flatten the extractor's parameters into the block csrc/uavenv_attention.hip expects (`Offsets` there): the six
+    shared-weight projections in MFMA fragment order, the sensor projection as channel-pair rows, biases / LayerNorm
+    parameters as they are."""
     def g(key):
         for name in _NAMES[key]:
             if name in state_dict:
@@ -29,19 +38,27 @@ def pack_attention_weights(state_dict, n_stack, device, out=None):
         raise KeyError(f"none of {_NAMES[key]} in state_dict")
     uav_w = g("uav_w")
     assert tuple(uav_w.shape) == (64, 3 * n_stack), (uav_w.shape, n_stack)
+    k0 = 16 * ((3 * n_stack + 15) // 16)                  # the encoder's K, zero padded to whole k-steps per lane group
+    uav_t = torch.zeros(k0, 64, dtype=torch.float32, device=device)
+    uav_t[:3 * n_stack] = uav_w.t()
     in_w, in_b = g("in_w"), g("in_b")
     wq, wk, wv = in_w[:64], in_w[64:128], in_w[128:]
-    sens_w = g("sens_w")
-    parts = [uav_w.t(), g("uav_b"), g("ln1_g"), g("ln1_b"), sens_w[:, 0], sens_w[:, 1], sens_w[:, 2], g("sens_b"),
-             wq.t(), in_b[:64], wk, in_b[64:128], wv.t(), in_b[128:], g("out_w").t(), g("out_b"), g("ln2_g"), g("ln2_b"),
-             g("fuse_w").t(), g("fuse_b")]
+    sens_w, sens_b = g("sens_w"), g("sens_b")
+    # [channel pair 32][sw0 pair, sw1 pair, sw2 pair, bias pair]
+    swp = torch.stack([sens_w[:, 0], sens_w[:, 1], sens_w[:, 2], sens_b], 0).reshape(4, 32, 2).permute(1, 0, 2)
+    fuse_t = g("fuse_w").t()
+    parts = [_frag(uav_t), g("uav_b"), g("ln1_g"), g("ln1_b"), swp,
+             _frag(wq.t()), in_b[:64],
+             torch.cat([_frag(wk[16 * h:16 * h + 16]) for h in range(4)]),       # per head: q_h -> the 64 embedding channels
+             _frag(wv.t()), in_b[128:], _frag(g("out_w").t()), g("out_b"), g("ln2_g"), g("ln2_b"),
+             _frag(fuse_t[:64]), _frag(fuse_t[64:]), g("fuse_b")]
     pieces = [p.contiguous().reshape(-1) for p in parts]
     if out is not None:                                   # refresh an existing block in place (same address: graph replays see it)
         assert out.numel() == sum(p.numel() for p in pieces)
         torch.cat(pieces, out=out)
         return out
     flat = torch.cat(pieces).contiguous()
-    assert flat.numel() == N.lib().uavenv_attention_weight_floats(n_stack)
+    assert flat.numel() == N.lib().uavenv_attention_weight_floats(n_stack), (flat.numel(), N.lib().uavenv_attention_weight_floats(n_stack))
     return flat
 
 

@@ -26,12 +26,12 @@ def flops_per_sample(k):
     return uav + q + qk + tokens + scores + mix + v + o + fuse
 
 
-out = {"note": "one wavefront per sample; weights (fp32) are re-read by every wavefront through L1 / L2"}
+out = {"note": "16 samples per workgroup; shared-weight projections on v_mfma_f32_16x16x4_f32, weights (fp32) read once per workgroup through L2"}
 for k in [int(a) for a in sys.argv[1:]] or [4, 10]:
     m = AttentionFeatures(k).cuda().eval()
     fused = U.FusedAttentionFeatures(m, k, "cuda:0")
     wfloats = fused.weights.numel()
-    for B in (256, 4096):
+    for B in (16, 256, 1024, 4096, 16384):
         x = torch.rand(B, k * 153, device="cuda")
 
         def t(f, n=300):
@@ -48,7 +48,7 @@ for k in [int(a) for a in sys.argv[1:]] or [4, 10]:
             eager, hip = t(m), t(fused)
         fl = flops_per_sample(k) * B
         hbm = (k * 153 * 4 + 128 * 4) * B + wfloats * 4                 # observations in, features out, weights once
-        cache = wfloats * 4 * B                                          # every wavefront streams the whole block
+        cache = wfloats * 4 * ((B + 15) // 16)                           # every workgroup reads the whole block once
         out[f"n_stack_{k}_batch_{B}"] = {
             "torch_eager_us": eager, "fused_hip_us": hip, "speedup": eager / hip,
             "flops": fl, "achieved_TFLOPs": fl / (hip * 1e-6) / 1e12, "frac_of_fp32_vector_peak": fl / (hip * 1e-6) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
