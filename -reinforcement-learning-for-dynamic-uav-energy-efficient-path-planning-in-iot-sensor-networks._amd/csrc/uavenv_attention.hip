@@ -15,9 +15,9 @@
 //     (lane l's A fragments of a K = 64 product are 16 consecutive floats of chunk l);
 //   * what is different per sample -- the 64 x 50 matrix e[i][s] = relu(W_s[i] . token_s + b[i]), the scores
 //     sum_i qk_h[i] e[i][s], the masked softmax and the mix sum_s a_h[s] e[i][s] -- belongs to wavefront w = sample w
-//     (lane = token, then lane = channel): e on the vector ALU (packed f32 over channel pairs; its wave-uniform operands come
-//     through scalar loads), the two contractions over it on v_mfma_f32_4x4x1_16b_f32 with rows = heads, one instruction per
-//     channel / token: ~5 vector + 1 matrix instruction per (channel, 64 tokens) where round 2's readlane + fma form took ~16.
+//     (lane = token, then lane = channel) on the vector ALU, as packed-f32 arithmetic over channel / token PAIRS with the
+//     wave-uniform operands arriving through scalar loads (sensor projection) or broadcast LDS reads (folded query, attention
+//     weights, tokens): 10 vector instructions per pair where round 2's readlane + fma form took ~31.
 // Nothing is materialised: the K/V projections are folded algebraically,
 //     score[s,h] = (Wk_h^T q_h) . e_s (+ q_h . bk_h, constant over s: it cancels in the softmax and is dropped)
 //     context_h = Wv_h (sum_s a[s,h] e_s) + bv_h
@@ -57,17 +57,16 @@ constexpr int kM = 16;                 // samples per workgroup = rows of every 
 constexpr int kChunk = 20;             // floats per chunk of a fragment-order buffer: 16 used + 4 of padding (80 B: an odd number
                                        // of 16-byte slots, so the 16 lanes of a ds_read_b128 group hit 16 different slots)
 constexpr int kBuf = 64 * kChunk;      // one [16 samples x 64 channels] activation buffer in fragment order
-constexpr int kQkHead = 68;            // folded queries of one (sample, head): 64 channels + 4 of padding (the four heads' rows
-constexpr int kQkStride = 4 * kQkHead; //   start in different 16-byte slots: lanes of different heads read them with one ds_read_b128)
-constexpr int kPairRow = 8;            // floats per channel pair of the packed sensor projection
-constexpr int kAHead = 56;             // attention weights of one head: 50 tokens, zero padded to 52, + 4 of padding (as above)
-constexpr int kScratch = 4 * kAHead;   // per wavefront: its sample's attention weights [head 4][56]
+constexpr int kQkStride = 256;         // folded queries per sample: [channel pair 32][head 4][2]
+constexpr int kPairRow = 8;            // floats per token pair / channel pair row of the sweep operands
+constexpr int kScratch = 2 * 25 * kPairRow;   // per wavefront: attention weights [25 token pairs][head 4][2] + tokens [25][3 (+1)][2]
 
 // LDS map (floats)
 constexpr int L_X = 0, L_Q0 = L_X + kBuf, L_Q = L_Q0 + kBuf, L_CTX = L_Q + kBuf, L_AO = L_CTX + kBuf;
 constexpr int L_QK = L_AO + kBuf, L_MIX = L_QK + kM * kQkStride;
 constexpr int kThreads = 1024;        // 16 wavefronts
-constexpr int L_SCR = L_MIX + kHeads * kBuf, L_TOTAL = L_SCR + 16 * kScratch;
+constexpr int L_SWP = L_MIX + kHeads * kBuf;                      // the sensor projection as channel-pair rows (mix sweep: lane = channel)
+constexpr int L_SCR = L_SWP + 32 * kPairRow, L_TOTAL = L_SCR + 16 * kScratch;
 
 template <int CTRL> __device__ __forceinline__ float dpp(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
@@ -94,6 +93,8 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 splat(float v) { f32x2 r = {v, v}; return r; }
+__device__ __forceinline__ f32x2 lo(f32x4 v) { f32x2 r = {v.x, v.y}; return r; }
+__device__ __forceinline__ f32x2 hi(f32x4 v) { f32x2 r = {v.z, v.w}; return r; }
 // what one wavefront wrote to its own LDS scratch becomes visible to its other lanes (no workgroup barrier: the scratch is private)
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(kThreads) void uav_attention_kernel(const float* __
         const int n_uav = 3 * n_stack, k0 = 4 * o.kt0;
         if (lane < k0) lds[L_X + ((lane / o.kt0) * 16 + w) * kChunk + lane % o.kt0] = (own && lane < n_uav) ? x[(lane / 3) * kFrame + lane % 3] : 0.0f;
         if (own && tok) { const float* cur = x + (size_t)(n_stack - 1) * kFrame + 3 + 3 * lane; t0 = cur[0]; t1 = cur[1]; t2 = cur[2]; }
+        if (tid < 32 * kPairRow) lds[L_SWP + tid] = W[o.swp + tid];
     }
     __syncthreads();
     ATTN_PHASE(0);
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(kThreads) void uav_attention_kernel(const float* __
         a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bk.z, a0, 0, 0, 0);
         a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bk.w, a1, 0, 0, 0);
         const f32x4 r = a0 + a1;
-        float* p = lds + L_QK + (4 * g) * kQkStride + h3 * kQkHead + i;                                         // [sample][head][channel]
+        float* p = lds + L_QK + (4 * g) * kQkStride + (i >> 1) * kPairRow + 2 * h3 + (i & 1);                   // [sample][pair][head][2]
         p[0] = r.x; p[kQkStride] = r.y; p[2 * kQkStride] = r.z; p[3 * kQkStride] = r.w;
     }
     // the value projection's fragments for after the sweeps
@@ -255,17 +257,19 @@ __global__ __launch_bounds__(kThreads) void uav_attention_kernel(const float* __
     ATTN_PHASE(3);
     ATTN_STAMP(3);
 
-    // ---- 4. this wavefront's sample: scores over the 50 tokens, masked softmax, attention-weighted token mix (dqn.py:616-637).
-    //         e[i][s] = relu(W_s[i] . token_s + b[i]) is evaluated on the vector ALU, with its wave-uniform operands (the sensor
-    //         projection in the score sweep, the tokens in the mix sweep) arriving through SCALAR loads; the two contractions
-    //         over it run on v_mfma_f32_4x4x1_16b_f32 (16 blocks of a 4 x 4 outer product: D[r][lane] += A[lane 4*(l/4)+r] * B[lane],
-    //         tools/check_mfma4x4.hip): rows = heads, lanes = tokens (scores) or channels (mix), one instruction per channel /
-    //         token, the A operand = this lane's head (l & 3) of the folded query / of the attention weights, held in registers.
-    //         (The first form of this phase read every uniform operand with broadcast ds_read_b128: a broadcast read occupies the
-    //         LDS as long as a full-width one, and 16 wavefronts x 230 of them made the phase LDS-bound: 8.2 us of the kernel's 14.)
+    // ---- 4. this wavefront's sample: scores over the 50 tokens, masked softmax, attention-weighted token mix (dqn.py:616-637),
+    //         as packed-f32 arithmetic over channel pairs (scores: lane = token) and token pairs (mix: lane = channel): 6 vector
+    //         instructions for a pair of e[i][s] = relu(W_s[i] . token_s + b[i]) and 4 for its contribution to the four heads.
+    //         Every operand that is uniform over the wavefront has to be broadcast: the sensor projection of the score sweep comes
+    //         through SCALAR loads (the packed block is read-only), the folded query / the attention weights / the token pairs of
+    //         the mix sweep through broadcast ds_read_b128 -- which occupy the LDS as long as full-width reads, so they are what
+    //         this phase is bound by together with the vector ALU (v_mfma_f32_4x4x1_16b_f32 with rows = heads
+    //         was tried for the two contractions: correct, no LDS traffic, but the instruction occupies the matrix pipe for ~64
+    //         cycles on gfx950 -- an eighth of the f32 MFMA rate -- and the phase took the same 8 us).
     {
         typedef const __attribute__((address_space(4))) float* cptr;        // constant address space: uniform loads become s_load
-        float* As = lds + L_SCR + w * kScratch;
+        float* As = lds + L_SCR + w * kScratch;            // [token pair 25][head 4][2]
+        float* Ts = As + 25 * kPairRow;                    // [token pair 25][t0 pair, t1 pair, t2 pair, -]
         float* mixp = lds + L_MIX + ((lane >> 4) * 16 + w) * kChunk + c16;
         if (!own) {
 #pragma unroll
@@ -275,72 +279,60 @@ __global__ __launch_bounds__(kThreads) void uav_attention_kernel(const float* __
             bool masked = !tok || (fabsf(t0) + fabsf(t1) + fabsf(t2) < 1e-6f) || (t2 < 1e-6f);
             const bool all_masked = __ballot(tok && !masked) == 0ull;
             masked = tok ? (masked && !all_masked) : true;
+            float* tp = Ts + (lane >> 1) * kPairRow + (lane & 1);
+            if (tok) { tp[0] = t0; tp[2] = t1; tp[4] = t2; }
 
             // scores: lane = token s, channel pairs (i, i+1)
-            float qa[kEmbed];
-            {
-                const float* qsrc = lds + L_QK + w * kQkStride + (lane & 3) * kQkHead;
-#pragma unroll
-                for (int t = 0; t < 16; t++) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(qsrc + 4 * t);
-                    qa[4 * t] = v.x; qa[4 * t + 1] = v.y; qa[4 * t + 2] = v.z; qa[4 * t + 3] = v.w;
-                }
-            }
-            const f32x2 t0s = splat(t0), t1s = splat(t1), t2s = splat(t2);
+            const f32x2 t0s = splat(t0), t1s = splat(t1), t2s = splat(t2), z2 = splat(0.0f);
             const cptr cw = (cptr)(W + o.swp);
-            f32x4 s0 = zero4, s1 = zero4;
-#pragma unroll
+            const f32x4* qk = reinterpret_cast<const f32x4*>(lds + L_QK + w * kQkStride);
+            f32x2 sc0 = z2, sc1 = z2, sc2 = z2, sc3 = z2;
+#pragma unroll 8
             for (int ip = 0; ip < 32; ip++) {
                 const f32x2 w0 = {cw[8 * ip], cw[8 * ip + 1]}, w1 = {cw[8 * ip + 2], cw[8 * ip + 3]};
                 const f32x2 w2 = {cw[8 * ip + 4], cw[8 * ip + 5]}, wb = {cw[8 * ip + 6], cw[8 * ip + 7]};
+                const f32x4 q01 = qk[2 * ip], q23 = qk[2 * ip + 1];
                 f32x2 e = w0 * t0s;
                 e = pk_fma(w1, t1s, e);
                 e = pk_fma(w2, t2s, e);
                 e = e + wb;
-                s0 = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[2 * ip], fmaxf(e.x, 0.0f), s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[2 * ip + 1], fmaxf(e.y, 0.0f), s1, 0, 0, 0);
+                e.x = fmaxf(e.x, 0.0f); e.y = fmaxf(e.y, 0.0f);
+                sc0 = pk_fma(lo(q01), e, sc0); sc1 = pk_fma(hi(q01), e, sc1);
+                sc2 = pk_fma(lo(q23), e, sc2); sc3 = pk_fma(hi(q23), e, sc3);
             }
             ATTN_STAMP(4);
-            const f32x4 scv = s0 + s1;
-            const float sc[kHeads] = {scv.x, scv.y, scv.z, scv.w};
+            const float sc[kHeads] = {sc0.x + sc0.y, sc1.x + sc1.y, sc2.x + sc2.y, sc3.x + sc3.y};
+            float* ap = As + (lane >> 1) * kPairRow + (lane & 1);
 #pragma unroll
             for (int h = 0; h < kHeads; h++) {                 // masked softmax over the tokens
                 const float v = masked ? -__builtin_inff() : sc[h];
                 const float m = wave_max(v);
                 const float p = masked ? 0.0f : __expf(v - m);
                 const float a = p * __builtin_amdgcn_rcpf(wave_sum(p));
-                if (lane < 52) As[h * kAHead + lane] = a;      // (lanes 50, 51: zero padding of the last k-steps)
+                if (tok) ap[2 * h] = a;
             }
             ATTN_STAMP(5);
-            wave_lds_sync();                                   // As is this wavefront's own: no workgroup barrier
+            wave_lds_sync();                                   // As / Ts are this wavefront's own: no workgroup barrier
 
-            // mix: lane = channel i; mix_h[i] = sum_s a_h[s] e[i][s]
-            float aa[52];
-            {
-                const float* asrc = As + (lane & 3) * kAHead;
-#pragma unroll
-                for (int t = 0; t < 13; t++) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(asrc + 4 * t);
-                    aa[4 * t] = v.x; aa[4 * t + 1] = v.y; aa[4 * t + 2] = v.z; aa[4 * t + 3] = v.w;
-                }
-            }
-            const float c_sw0 = cw[8 * (lane >> 1) + (lane & 1)], c_sw1 = cw[8 * (lane >> 1) + 2 + (lane & 1)];
-            const float c_sw2 = cw[8 * (lane >> 1) + 4 + (lane & 1)], c_sb = cw[8 * (lane >> 1) + 6 + (lane & 1)];
-            const cptr ct = (cptr)(obs + (size_t)sg_own * row + (size_t)(n_stack - 1) * kFrame + 3);
-            f32x4 m0 = zero4, m1 = zero4;
-#pragma unroll
+            // mix: lane = channel i; mix_h[i] = sum_s a_h[s] e[i][s] over token pairs (s, s+1)
+            const float* my = lds + L_SWP + (lane >> 1) * kPairRow + (lane & 1);
+            const f32x2 c_sw0 = splat(my[0]), c_sw1 = splat(my[2]), c_sw2 = splat(my[4]), c_sb = splat(my[6]);
+            const f32x4* a4 = reinterpret_cast<const f32x4*>(As);
+            const f32x4* t4 = reinterpret_cast<const f32x4*>(Ts);
+            f32x2 m0 = z2, m1 = z2, m2 = z2, m3 = z2;
+#pragma unroll 5
             for (int sp = 0; sp < 25; sp++) {
-                float e0 = __builtin_fmaf(c_sw0, ct[6 * sp], c_sb);
-                float e1 = __builtin_fmaf(c_sw0, ct[6 * sp + 3], c_sb);
-                e0 = __builtin_fmaf(c_sw1, ct[6 * sp + 1], e0);
-                e1 = __builtin_fmaf(c_sw1, ct[6 * sp + 4], e1);
-                e0 = __builtin_fmaf(c_sw2, ct[6 * sp + 2], e0);
-                e1 = __builtin_fmaf(c_sw2, ct[6 * sp + 5], e1);
-                m0 = __builtin_amdgcn_mfma_f32_4x4x1f32(aa[2 * sp], fmaxf(e0, 0.0f), m0, 0, 0, 0);
-                m1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aa[2 * sp + 1], fmaxf(e1, 0.0f), m1, 0, 0, 0);
+                const f32x4 ta = t4[2 * sp], a01 = a4[2 * sp], a23 = a4[2 * sp + 1];
+                const f32x2 tb = *reinterpret_cast<const f32x2*>(Ts + sp * kPairRow + 4);
+                f32x2 e = c_sw0 * lo(ta);
+                e = pk_fma(c_sw1, hi(ta), e);
+                e = pk_fma(c_sw2, tb, e);
+                e = e + c_sb;
+                e.x = fmaxf(e.x, 0.0f); e.y = fmaxf(e.y, 0.0f);
+                m0 = pk_fma(lo(a01), e, m0); m1 = pk_fma(hi(a01), e, m1);
+                m2 = pk_fma(lo(a23), e, m2); m3 = pk_fma(hi(a23), e, m3);
             }
-            const f32x4 mv = m0 + m1;
-            mixp[0] = mv.x; mixp[kBuf] = mv.y; mixp[2 * kBuf] = mv.z; mixp[3 * kBuf] = mv.w;
+            mixp[0] = m0.x + m0.y; mixp[kBuf] = m1.x + m1.y; mixp[2 * kBuf] = m2.x + m2.y; mixp[3 * kBuf] = m3.x + m3.y;
         }
     }
     ATTN_STAMP(6);
