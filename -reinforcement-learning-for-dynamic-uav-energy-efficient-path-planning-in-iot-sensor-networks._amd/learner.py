@@ -24,17 +24,23 @@ reference:
     SB3's predict() flips ONE coin for the whole vector of environments; with thousands of environments that is an
     artefact, so every environment flips its own (shared_exploration_coin=True restores SB3's behaviour).
 
-Launch-bound loops are replayed as HIP graphs (`use_graphs`, single process): one vector step of acting -- Q-network forward,
+Launch-bound loops are replayed as HIP graphs (`use_graphs`): one vector step of acting -- Q-network forward,
 epsilon-greedy choice, environment step into the ring slot, frame stack, target copy -- is ~15 launches of a few
 microseconds of GPU work each behind ~270 us of Python, and a gradient step ~150 launches behind ~2 ms; captured once per
 ring slot (the slot's pointers are baked into the launches) and once for the update, a vector step of the reference
-configuration costs what its kernels cost.  The eager paths stay (several ranks, tests of the arithmetic).
+configuration costs what its kernels cost.  The eager paths stay (CPU rings, tests of the arithmetic).
 
 Everything stays on the GPU: the step kernel writes observations and (action, reward, done, terminal ticket) straight
 into the TransitionRing, the frame stack for acting is the uavenv_frame_stack kernel, sampled batches gather their
-frame stacks from the ring (each frame stored once instead of 2 x n_stack times, dqn.py:1085's budget).  With
-torch.distributed initialised, every rank steps its own shard of environments, the ring all-gathers the transition blocks
-(BASELINE config 4) and gradients are averaged, so all ranks hold the same weights.
+frame stacks from the ring (each frame stored once instead of 2 x n_stack times, dqn.py:1085's budget).
+
+Several ranks (torch.distributed initialised; BASELINE config 4 as a training run): every rank steps its own shard of
+environments, the ring all-gathers the transition blocks chunk by chunk, and every rank draws batch_size / world samples of
+the SHARED ring for an update, so that one update still sees `batch_size` transitions (dqn.py:1086) -- the gradients are
+averaged with ONE all-reduce of a flat buffer and every rank applies the same Adam step: all replicas hold identical weights.
+Graph replay coexists with the exchange: the collectives are issued from the host between replays (the chunk's all-gather
+when its last slot has been stepped; the gradient all-reduce between the update's two graphs: sample -> loss -> backward ->
+flatten | clip -> Adam).
 """
 import copy
 import math
@@ -133,7 +139,7 @@ class DQNLearner:
                  learning_starts=25_000, exploration_fraction=0.25, exploration_final_eps=0.03, exploration_initial_eps=1.0,
                  target_update_interval=5_000, train_freq=4, gradient_steps=1, net_arch=(512, 512, 256), n_stack=4,
                  total_timesteps=3_000_000, max_grad_norm=10.0, extractor="mlp", shared_exploration_coin=False, seed=0,
-                 chunk_len=None, reward_scale=1.0, use_graphs=None, tune_gemms=None):
+                 chunk_len=None, reward_scale=1.0, use_graphs=None, tune_gemms=None, frame_stack_cls=FrameStack):
         """reward_scale (not an SB3 / reference option; default 1.0 = theirs): the environment's rewards reach 1e4-1e5 per
         step (+5000 per new sensor, 100 x bytes x urgency), which a smooth-L1 loss follows at one unit of gradient per
         sample -- the reference spends 750 k gradient steps on it.  Short runs (the tests) scale the reward in the loss."""
@@ -143,6 +149,9 @@ class DQNLearner:
         self.n_envs_total = self.E * self.world                   # SB3's n_envs: transitions per vector step
         self.lr_schedule = learning_rate if callable(learning_rate) else (lambda _p, v=float(learning_rate): v)
         self.batch_size, self.gamma, self.learning_starts = int(batch_size), float(gamma), int(learning_starts)
+        # every rank draws its share of the batch from the shared ring: one update = batch_size transitions in all (dqn.py:1086)
+        assert self.batch_size % self.world == 0, "batch_size must be divisible by the number of ranks"
+        self.local_batch = self.batch_size // self.world
         self.eps0, self.eps1, self.eps_fraction = float(exploration_initial_eps), float(exploration_final_eps), float(exploration_fraction)
         self.train_freq, self.gradient_steps = int(train_freq), int(gradient_steps)
         self.total_timesteps, self.max_grad_norm, self.k = int(total_timesteps), float(max_grad_norm), int(n_stack)
@@ -156,9 +165,10 @@ class DQNLearner:
         on_gpu = self.dev.type == "cuda"
         self.opt = torch.optim.Adam(self.q.parameters(), lr=torch.tensor(self.lr_schedule(1.0), device=self.dev) if on_gpu
                                     else self.lr_schedule(1.0), capturable=on_gpu, fused=on_gpu or None)
-        self.use_graphs = (on_gpu and self.world == 1) if use_graphs is None else bool(use_graphs)
-        assert not (self.use_graphs and self.world > 1), "graph replay is single-process (the chunk collectives are issued from the host)"
-        self._act_graphs, self._train_graph, self._fused = None, None, None
+        self.use_graphs = on_gpu if use_graphs is None else bool(use_graphs)
+        self._act_graphs, self._train_graph, self._train_graph_b, self._fused = None, None, None, None
+        # one flat buffer for the gradient all-reduce (world > 1)
+        self._flat_grad = torch.zeros(sum(p.numel() for p in self.q.parameters()), device=self.dev) if self.world > 1 else None
         # tune_gemms (default off): PyTorch's TunableOp picks the GEMM kernel per shape by timing the candidates the first time a
         # shape is seen (the eager steps before the captures).  The update is a dozen float32 GEMMs of batch 256 whose default
         # kernels leave most of the 256 CUs idle (14-29 us each): 599 -> 348 us per update (1 491 -> 864 us with the attention
@@ -182,7 +192,7 @@ class DQNLearner:
         capacity = (math.ceil(slots / L) + 1) * L
         self.ring = TransitionRing(capacity, self.E, self.D, self.dev, world_size=self.world, rank=self.rank, chunk_len=L)
         self.ring.attach(env)
-        self.fs = FrameStack(self.E, self.D, self.k, self.dev)
+        self.fs = frame_stack_cls(self.E, self.D, self.k, self.dev)
         self.num_timesteps, self.n_calls, self.n_updates = 0, 0, 0
         self.last_loss = None
         self._stacked = None
@@ -277,38 +287,72 @@ class DQNLearner:
         self._act_graphs = graphs
         self._act_epoch = self.env.launch_epoch
 
+    def _flatten_grads(self):
+        off = 0
+        for p in self.q.parameters():
+            n = p.numel()
+            self._flat_grad[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+
+    def _unflatten_grads(self):
+        off = 0
+        for p in self.q.parameters():
+            n = p.numel()
+            p.grad.copy_(self._flat_grad[off:off + n].view_as(p.grad))
+            off += n
+
+    def _allreduce_grads(self):
+        """ONE collective for all gradients; afterwards every rank holds the mean over ranks = the gradient of the mean loss
+        over the world's batch_size transitions."""
+        dist.all_reduce(self._flat_grad)
+        self._flat_grad.div_(self.world)
+
     def _capture_train_graph(self):
         """One gradient step -- sample, TD loss, backward, clip, Adam -- as a graph.  Captured after eager updates have run
         (optimizer state and library workspaces exist); the ring's sampling window and the learning rate are device scalars
-        refreshed before each replay."""
+        refreshed before each replay.  With several ranks the step is TWO graphs around the host-issued gradient all-reduce:
+        [sample -> loss -> backward -> flatten] and [unflatten -> clip -> Adam]."""
         self._g_win = (torch.zeros((), dtype=torch.int64, device=self.dev), torch.zeros((), dtype=torch.int64, device=self.dev))
         self._g_loss = torch.zeros((), device=self.dev)
-        self._g_index = torch.zeros(4, self.batch_size, dtype=torch.int64, device=self.dev)    # the last replay's draw (tests)
+        self._g_index = torch.zeros(4, self.local_batch, dtype=torch.int64, device=self.dev)    # the last replay's draw (tests)
         n, oldest = self.ring.window_state()
         self._g_win[0].fill_(n); self._g_win[1].fill_(oldest)
         params = list(self.q.parameters())
+        self.ring.drain()                                 # (inside the capture sample_stacked must not wait on collectives)
         torch.cuda.synchronize(self.dev)
         g = torch.cuda.CUDAGraph()
         g.register_generator_state(self.gen)
-        with torch.cuda.graph(g):
-            batch = self.ring.sample_stacked(self.batch_size, self.k, generator=self.gen, window=self._g_win)
+        pool = torch.cuda.graph_pool_handle()
+        with torch.cuda.graph(g, pool=pool):
+            batch = self.ring.sample_stacked(self.local_batch, self.k, generator=self.gen, window=self._g_win)
             loss = td_loss(self.q, self.q_target, batch, self.gamma, self.reward_scale)
-            self.opt.zero_grad(set_to_none=True)
+            self.opt.zero_grad(set_to_none=self.world == 1)   # (several ranks: the gradient tensors are part of both graphs)
             loss.backward()
-            nn.utils.clip_grad_norm_(params, self.max_grad_norm)
-            self.opt.step()
             self._g_loss.copy_(loss.detach())
             self._g_index.copy_(torch.stack(batch["index"]))
-            if self._fused is not None:
-                self._fused.refresh(self.q.features)
+            if self.world > 1:
+                self._flatten_grads()
+            else:
+                nn.utils.clip_grad_norm_(params, self.max_grad_norm)
+                self.opt.step()
+                if self._fused is not None:
+                    self._fused.refresh(self.q.features)
         self._train_graph = g
+        if self.world > 1:
+            gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gb, pool=pool):
+                self._unflatten_grads()
+                nn.utils.clip_grad_norm_(params, self.max_grad_norm)
+                self.opt.step()
+                if self._fused is not None:
+                    self._fused.refresh(self.q.features)
+            self._train_graph_b = gb
         if self.tune_gemms and self._act_graphs is not None:
             import torch.cuda.tunable as tunable
             tunable.tuning_enable(False)                  # every shape of the two loops has been seen
 
     def _graphs_usable(self):
-        return (self.use_graphs and self.dev.type == "cuda" and self.world == 1 and self.ring.capacity <= self._GRAPH_SLOT_LIMIT
-                and not self.ring.exchange)
+        return self.use_graphs and self.dev.type == "cuda" and self.ring.capacity <= self._GRAPH_SLOT_LIMIT
 
     def collect(self, vector_steps):
         """SB3 collect_rollouts: `vector_steps` steps of every environment into the replay ring."""
@@ -344,23 +388,27 @@ class DQNLearner:
         if self._graphs_usable() and self._train_graph is None and self.n_updates >= 3:
             self._capture_train_graph()
         if self._train_graph is not None:
+            self.ring.drain()                              # the gathers of finished chunks (host side; no-op alone)
             n, oldest = self.ring.window_state()
             self._g_win[0].fill_(n); self._g_win[1].fill_(oldest)
             for _ in range(steps):
                 self._train_graph.replay()
+                if self._train_graph_b is not None:
+                    self._allreduce_grads()
+                    self._train_graph_b.replay()
                 self.n_updates += 1
             self.last_loss = self._g_loss
             return self._g_loss
         loss = None
         for _ in range(steps):
-            batch = self.ring.sample_stacked(self.batch_size, self.k, generator=self.gen)
+            batch = self.ring.sample_stacked(self.local_batch, self.k, generator=self.gen)
             loss = td_loss(self.q, self.q_target, batch, self.gamma, self.reward_scale)
-            self.opt.zero_grad(set_to_none=True)
+            self.opt.zero_grad(set_to_none=False if self.world > 1 else True)
             loss.backward()
-            if self.world > 1:                                     # replicas stay identical: average the gradients
-                for p in self.q.parameters():
-                    dist.all_reduce(p.grad)
-                    p.grad.div_(self.world)
+            if self.world > 1:                                     # replicas stay identical: one all-reduce of the flat gradient
+                self._flatten_grads()
+                self._allreduce_grads()
+                self._unflatten_grads()
             nn.utils.clip_grad_norm_(self.q.parameters(), self.max_grad_norm)
             self.opt.step()
             self.n_updates += 1

@@ -339,7 +339,8 @@ class TransitionRing:
         so the replay stores each frame ONCE instead of n_stack times (dqn.py:1085 budgets 2 x 612 floats per
         transition for the stacked copies)."""
         assert self.sampleable() >= 2
-        self.drain()
+        if window is None:
+            self.drain()            # (a captured draw -- `window` given -- is replayed later: its caller drains before each replay)
         return self.stacked_batch_at(*self._draw(batch_size, generator, window), n_stack)
 
     def stacked_batch_at(self, j, slot, r, e, n_stack):

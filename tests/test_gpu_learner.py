@@ -6,6 +6,7 @@ checked here: (a) the arithmetic of one update -- TD target, smooth-L1, masking,
 target-network cadence, the schedules -- against formulas written out by hand; (b) that a short run actually learns.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -253,3 +254,75 @@ def test_attention_learner_acts_through_the_fused_kernel_with_current_weights():
     got = L._fused(L.fs.stacked)
     assert torch.allclose(got, want, rtol=2e-4, atol=2e-5), float((got - want).abs().max())
     env.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# several ranks on ONE GPU (gloo): the real environment, HIP graphs and the chunk exchange together
+# ---------------------------------------------------------------------------------------------------------------
+def _two_rank_gpu_worker(rank, world, port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import uavenv_amd as U
+    from uavenv_amd import learner as LR
+    torch.cuda.set_device(0)
+    E = 64
+    bad = []
+
+    def check(name, cond):
+        if not cond:
+            bad.append(name)
+    env = U.BatchedUAVEnv(E, env_index_base=rank * E, num_sensors=10, grid_size=(40, 40), max_steps=25, seed=4)
+    L = LR.DQNLearner(env, learning_rate=1e-3, buffer_size=2 * E * 48, batch_size=64, learning_starts=0, target_update_interval=2 * E * 5,
+                      train_freq=4, gradient_steps=1, net_arch=(64, 64), n_stack=3, total_timesteps=10**6, seed=9, chunk_len=8,
+                      reward_scale=1e-3)
+    check("setup", L.world == 2 and L.local_batch == 32 and L.ring.exchange and L._graphs_usable())
+    L.learn(total_timesteps=2 * E * 4 * 30)                  # 120 vector steps: > 2 revolutions of the 56-slot ring, 4 auto-resets per env
+    torch.cuda.synchronize()
+    check("graphs", L._act_graphs is not None and L._train_graph is not None and L._train_graph_b is not None)
+    check(f"updates {L.n_updates}", L.n_updates >= 25)
+    # replicas identical
+    flat = torch.cat([p.detach().reshape(-1) for p in L.q.parameters()]).cpu()
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    check(f"replicas differ by {float((both[0] - both[1]).abs().max())}", torch.equal(both[0], both[1]))
+    check("finite", bool(torch.isfinite(flat).all()))
+    # every gathered chunk part is the same on both ranks: sums of the (chunk, rank) parts, head chunk excluded
+    L.ring.drain()
+    torch.cuda.synchronize()
+    sums = L.ring._i32.long().sum(-1).cpu()                 # [chunk][rank], over the raw words (ticket -1 is a NaN as float)
+    head_chunk = L.ring.head // L.ring.L
+    keep = [c for c in range(L.ring.n_chunks) if c != head_chunk]
+    views = [torch.zeros_like(sums) for _ in range(world)]
+    dist.all_gather(views, sums)
+    check("rings equal", torch.equal(views[0][keep], views[1][keep]))
+    check("rings filled", bool((sums[keep] != 0).all()))
+    # episode ends of the OTHER rank are valid transitions here (terminal rows travelled with the chunks)
+    b = L.ring.sample_stacked(4000, 3, generator=torch.Generator(device="cuda").manual_seed(1))
+    j, slot, r, e = b["index"]
+    remote_end = (r == 1 - rank) & b["done"]
+    check(f"remote ends {int(remote_end.sum())}", int(remote_end.sum()) > 10)
+    check("remote ends valid", bool(b["valid"][remote_end].all()))
+    dist.barrier()
+    dist.destroy_process_group()
+    env.close()
+    q.put((rank, bad))
+
+
+def test_two_rank_learner_on_one_gpu_graphs_coexist_with_the_exchange():
+    """BASELINE config 4 as a training run, rehearsed with two ranks on this one GPU over gloo: per-slot act graphs and the
+    two-graph update are replayed while the chunk all-gathers and the flat gradient all-reduce are issued from the host between
+    them; the replicas must end with bit-identical weights and identical rings."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_two_rank_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, []), (1, [])], res

@@ -2,6 +2,7 @@
 for the reference's hyper-parameters (agents/dqn/dqn.py:1077-1099), the TD loss with its validity mask, and the network shapes.
 The loops themselves need the environment (a GPU): tests/test_gpu_learner.py."""
 import math
+import os
 
 import pytest
 import torch
@@ -55,3 +56,80 @@ def test_q_network_shapes_follow_sb3_mlp_policy_and_the_attention_extractor():
     assert qa.features.features_dim == 128 and qa(torch.rand(2, 1530)).shape == (2, 5)
     n_params = sum(p.numel() for p in qa.features.parameters())
     assert n_params == (30 * 64 + 64) + 2 * 64 + (3 * 64 + 64) + (3 * 64 * 64 + 3 * 64) + (64 * 64 + 64) + 2 * 64 + (128 * 128 + 128)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# several ranks (BASELINE config 4 as a training run), on CPU over gloo with the doubles of tests/learner_doubles.py
+# ---------------------------------------------------------------------------------------------------------------
+def _learner_worker(rank, world, port, q):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    import torch.distributed as dist
+    import uavenv_amd  # noqa: F401
+    from uavenv_amd import learner as LR
+    from learner_doubles import ToyEnv, TorchFrameStack
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    E, D, k = 6, 12, 3
+    env = ToyEnv(E, D, rank=rank, period=7)
+    L = LR.DQNLearner(env, learning_rate=1e-2, buffer_size=2 * E * 40, batch_size=32, gamma=0.9, learning_starts=0,
+                      target_update_interval=2 * E * 6, train_freq=4, gradient_steps=1, net_arch=(16, 8), n_stack=k,
+                      total_timesteps=10**6, seed=11, chunk_len=4, frame_stack_cls=TorchFrameStack)
+    ok = L.world == world and L.local_batch == 32 // world and L.n_envs_total == E * world and not L._graphs_usable()
+    init = [p.detach().clone() for p in L.q.parameters()]
+    L.learn(total_timesteps=2 * E * 4 * 7)                 # 7 rollouts of 4 vector steps; updates start once k + 2 slots are visible
+    ok &= L.n_updates >= 5 and L.n_calls == 28
+    # (1) replicas: bit-identical weights on every rank after the updates, and they did change
+    flat = torch.cat([p.detach().reshape(-1) for p in L.q.parameters()])
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    ok &= all(torch.equal(both[0], b) for b in both[1:])
+    ok &= any(not torch.equal(a, b.detach()) for a, b in zip(init, L.q.parameters()))
+    # (2) the ranks drew DIFFERENT batches (own generators) of batch_size / world transitions each
+    ok &= L.gen.initial_seed() == 11 * 7919 + 13 + rank
+    # (3) this rank's ring holds the other rank's transitions, episode ends with their terminal rows included
+    ring, other = L.ring, 1 - rank
+    L.ring.drain()
+    n, oldest = ring.window_state()
+    seen_remote_end = 0
+    for j in range(n - 1):
+        slot = (oldest + j) % ring.capacity
+        nxt = (slot + 1) % ring.capacity
+        for e in range(E):
+            o = ring.obs_at(slot, other, e)
+            t = round(float(o[0] % 1) * 1000)
+            ok &= int(o[0]) == 1000 * other + e                                      # the other rank's env e, step t
+            aux = ring.aux_at(nxt, other, e)
+            ended = (t + 1 + e + other) % 7 == 0
+            ok &= bool(aux[2] > 0.5) == ended
+            if ended:
+                tk = int(ring.tickets_at(nxt, other, e))
+                row = ring.terminal_at(nxt, other, tk)
+                ok &= tk >= 0 and abs(float(row[0]) - (1000 * other + e + (t + 1) / 1000 + 0.5)) < 1e-3
+                seen_remote_end += 1
+    ok &= seen_remote_end >= 3
+    b = ring.sample_stacked(400, k, generator=torch.Generator().manual_seed(3))
+    src = torch.floor(b["obs"][:, -D] / 1000)                                        # newest frame's rank tag
+    ok &= bool((src == other).any()) and bool((src == rank).any()) and bool(b["valid"].all())
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, bool(ok)))
+
+
+def test_two_rank_learner_keeps_replicas_identical_and_shares_the_ring():
+    """BASELINE config 4 as training: each rank steps its shard, the ring all-gathers chunks (terminal sections included),
+    every rank draws batch_size / world samples, ONE flat all-reduce averages the gradients: identical weights everywhere."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_learner_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
