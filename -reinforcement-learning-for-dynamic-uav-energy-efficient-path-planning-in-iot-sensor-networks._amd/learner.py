@@ -113,6 +113,15 @@ class QNetwork(nn.Module):
         return self.head(self.features(x))
 
 
+def tunable_cache_path(device):
+    """Where the TunableOp results for `device` are kept: $UAVENV_CACHE_DIR (default ~/.cache/uavenv_amd) /
+    tunableop_<device model>_<torch version>.csv -- GEMM choices depend on the chip and the library build, not on the process."""
+    root = os.environ.get("UAVENV_CACHE_DIR") or os.path.join(os.path.expanduser("~"), ".cache", "uavenv_amd")
+    name = torch.cuda.get_device_name(device) if torch.cuda.is_available() else "cpu"
+    tag = "".join(c if c.isalnum() else "_" for c in f"{name}_{torch.__version__}")
+    return os.path.join(root, f"tunableop_{tag}.csv")
+
+
 def linear_epsilon(progress_remaining, initial, final, fraction):
     """SB3 get_linear_fn(initial, final, fraction)(progress_remaining)."""
     done = 1.0 - progress_remaining
@@ -139,7 +148,8 @@ class DQNLearner:
                  learning_starts=25_000, exploration_fraction=0.25, exploration_final_eps=0.03, exploration_initial_eps=1.0,
                  target_update_interval=5_000, train_freq=4, gradient_steps=1, net_arch=(512, 512, 256), n_stack=4,
                  total_timesteps=3_000_000, max_grad_norm=10.0, extractor="mlp", shared_exploration_coin=False, seed=0,
-                 chunk_len=None, reward_scale=1.0, use_graphs=None, tune_gemms=None, frame_stack_cls=FrameStack):
+                 chunk_len=None, reward_scale=1.0, use_graphs=None, tune_gemms=None, frame_stack_cls=FrameStack,
+                 updates_per_transition=None):
         """reward_scale (not an SB3 / reference option; default 1.0 = theirs): the environment's rewards reach 1e4-1e5 per
         step (+5000 per new sensor, 100 x bytes x urgency), which a smooth-L1 loss follows at one unit of gradient per
         sample -- the reference spends 750 k gradient steps on it.  Short runs (the tests) scale the reward in the loss."""
@@ -154,6 +164,15 @@ class DQNLearner:
         self.local_batch = self.batch_size // self.world
         self.eps0, self.eps1, self.eps_fraction = float(exploration_initial_eps), float(exploration_final_eps), float(exploration_fraction)
         self.train_freq, self.gradient_steps = int(train_freq), int(gradient_steps)
+        # SB3: gradient_steps = -1 means "as many updates as transitions collected in the rollout".  The reference (4 environments,
+        # train_freq 4, gradient_steps 1) makes ONE update per 16 transitions; with thousands of environments gradient_steps = 1
+        # is one update per train_freq * n_envs transitions -- 1 / 16 384 at 4096 environments: a loop that steps fast and learns
+        # nothing.  `updates_per_transition` states the ratio directly (1 / 16 = the reference's) and overrides gradient_steps.
+        if updates_per_transition is not None:
+            self.gradient_steps = max(1, round(float(updates_per_transition) * self.train_freq * self.n_envs_total))
+        elif self.gradient_steps < 0:
+            self.gradient_steps = self.train_freq * self.n_envs_total
+        self.updates_per_transition = self.gradient_steps / float(self.train_freq * self.n_envs_total)
         self.total_timesteps, self.max_grad_norm, self.k = int(total_timesteps), float(max_grad_norm), int(n_stack)
         self.target_every = max(int(target_update_interval) // self.n_envs_total, 1)     # vector steps (SB3 DQN._on_step)
         self.shared_coin = bool(shared_exploration_coin)
@@ -169,19 +188,26 @@ class DQNLearner:
         self._act_graphs, self._train_graph, self._train_graph_b, self._fused = None, None, None, None
         # one flat buffer for the gradient all-reduce (world > 1)
         self._flat_grad = torch.zeros(sum(p.numel() for p in self.q.parameters()), device=self.dev) if self.world > 1 else None
-        # tune_gemms (default off): PyTorch's TunableOp picks the GEMM kernel per shape by timing the candidates the first time a
-        # shape is seen (the eager steps before the captures).  The update is a dozen float32 GEMMs of batch 256 whose default
-        # kernels leave most of the 256 CUs idle (14-29 us each): 599 -> 348 us per update (1 491 -> 864 us with the attention
-        # extractor), 13.8 -> 17.6 M and 7.2 -> 9.9 M timesteps/s.  The tuning itself takes 3 s (13 s with the attention
-        # extractor) -- more than the reference's whole 3 M-timestep run lasts here -- hence opt-in, for long runs.  It is a
-        # process-wide PyTorch switch; tuning is switched off again once both graphs exist (the chosen kernels stay in use).
-        self.tune_gemms = False if tune_gemms is None else bool(tune_gemms)
-        if self.tune_gemms and on_gpu:
+        # tune_gemms: PyTorch's TunableOp picks the GEMM kernel per shape by timing the candidates the first time a shape is seen
+        # (the eager steps before the captures).  The update is a dozen float32 GEMMs of batch 256 whose default kernels leave
+        # most of the 256 CUs idle (14-29 us each): 599 -> 348 us per update (1 491 -> 864 us with the attention extractor).
+        # The tuning itself takes 3 s (13 s with the attention extractor), so its results are PERSISTED: one file per device
+        # model and PyTorch build under the cache directory (tunable_cache_path), read back by the next process -- which then
+        # tunes only shapes it has not seen -- and written again once both graphs exist.  None (default) = use the cache when
+        # there is one, tune from scratch only for runs long enough to pay for it (>= 20 M timesteps); True / False force it.
+        # It is a process-wide PyTorch switch; tuning is switched off again once both graphs exist (the chosen kernels stay).
+        self._tune_path = tunable_cache_path(self.dev) if on_gpu else None
+        if tune_gemms is None:
+            tune_gemms = on_gpu and (os.path.exists(self._tune_path) or self.total_timesteps >= 20_000_000)
+        self.tune_gemms = bool(tune_gemms) and on_gpu
+        if self.tune_gemms:
             import torch.cuda.tunable as tunable
             tunable.enable(True)
             tunable.tuning_enable(True)
             try:
-                tunable.set_filename(os.devnull)          # keep the results in memory: no tunableop_results*.csv in the cwd
+                os.makedirs(os.path.dirname(self._tune_path), exist_ok=True)
+                tunable.set_filename(self._tune_path)          # read at the first GEMM when it exists (validated against the
+                tunable.write_file_on_exit(False)               # library versions it was made with); written by _finish_tuning
             except Exception:
                 pass
         self.gen = torch.Generator(device=self.dev).manual_seed(seed * 7919 + 13 + self.rank)
@@ -348,8 +374,18 @@ class DQNLearner:
                     self._fused.refresh(self.q.features)
             self._train_graph_b = gb
         if self.tune_gemms and self._act_graphs is not None:
-            import torch.cuda.tunable as tunable
-            tunable.tuning_enable(False)                  # every shape of the two loops has been seen
+            self._finish_tuning()                         # every shape of the two loops has been seen
+
+    def _finish_tuning(self):
+        """Stop timing candidates and persist what was chosen (atomically: several ranks / processes may share the cache)."""
+        import torch.cuda.tunable as tunable
+        tunable.tuning_enable(False)
+        try:
+            tmp = f"{self._tune_path}.{os.getpid()}.tmp"
+            if tunable.write_file(tmp):
+                os.replace(tmp, self._tune_path)
+        except Exception:
+            pass
 
     def _graphs_usable(self):
         return self.use_graphs and self.dev.type == "cuda" and self.ring.capacity <= self._GRAPH_SLOT_LIMIT
@@ -463,3 +499,42 @@ class DQNLearner:
             stacked = fs.step(o, d, eval_env.terminal_obs)
         allr = torch.cat(returns)
         return float(allr.mean()), int(allr.numel())
+
+    @torch.no_grad()
+    def evaluate_episodes(self, eval_env, policy="greedy", max_steps=4200):
+        """One complete episode of every environment of `eval_env` (auto-reset on) under `policy` -- "greedy" (argmax Q, SB3
+        predict(deterministic=True)), "random", or an on-device heuristic id (_native.POLICY_NEAREST / _MAX_THROUGHPUT_V2) -- and
+        what the reference's curriculum gate looks at (dqn.py:921-984): means of the episode return, NDR (% of sensors visited),
+        Jain's index, bytes collected and episode length over the environments' FIRST episodes."""
+        E = eval_env.num_envs
+        fs = FrameStack(E, eval_env.obs_dim, self.k, self.dev)
+        stacked = fs.reset(eval_env.reset())
+        finished = torch.zeros(E, dtype=torch.bool, device=self.dev)
+        first = None
+        gen = torch.Generator(device=self.dev).manual_seed(12345)
+        for _ in range(max_steps):
+            if policy == "greedy":
+                a = self.q(stacked).argmax(1).to(torch.int32)
+                o, r, d = eval_env.step(a)
+            elif policy == "random":
+                o, r, d = eval_env.step(torch.randint(0, 5, (E,), device=self.dev, dtype=torch.int32, generator=gen))
+            else:
+                o, r, d = eval_env.step_policy(int(policy))
+            stacked = fs.step(o, d, eval_env.terminal_obs)
+            db = d.bool()
+            newly = db & ~finished
+            if bool(newly.any()):
+                st = eval_env.episode_stats()
+                if first is None:
+                    first = st.copy()
+                idx = newly.cpu().numpy()
+                first[idx] = st[idx]
+                finished |= db
+                if bool(finished.all()):
+                    break
+        assert first is not None and bool(finished.all()), "not every environment finished an episode"
+        return {"episodes": int(E), "mean_return": float(first["episode_return"].mean()),
+                "ndr": float((first["sensors_visited"] / first["num_sensors"] * 100).mean()),
+                "jains": float(first["jains_index"].mean()), "mean_collected_bytes": float(first["total_collected"].mean()),
+                "mean_lost_bytes": float(first["total_lost"].mean()), "mean_episode_length": float(first["length"].mean())}
+

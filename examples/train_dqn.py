@@ -35,7 +35,8 @@ def main():
     ap.add_argument("--gradient-steps", type=int, default=1, help="updates per rollout of train_freq vector steps (SB3 default 1)")
     ap.add_argument("--reward-scale", type=float, default=1.0)
     ap.add_argument("--domain-rand", action="store_true")
-    ap.add_argument("--tune-gemms", action="store_true", help="let PyTorch's TunableOp pick the update's GEMM kernels (seconds of tuning; pays off on long runs)")
+    ap.add_argument("--tune-gemms", action="store_true", help="let PyTorch's TunableOp pick the update's GEMM kernels even without a cache (seconds of tuning, persisted under $UAVENV_CACHE_DIR; by default a cache is used when present)")
+    ap.add_argument("--updates-per-transition", type=float, default=None, help="e.g. 0.0625 = the reference's one update per 16 transitions (overrides --gradient-steps)")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
@@ -48,7 +49,7 @@ def main():
         kw.update(grid_size=(500, 500))
     env = U.BatchedUAVEnv(args.envs, flags=flags, **kw)
     hp = dict(REFERENCE_HYPERPARAMS, n_stack=args.n_stack, total_timesteps=args.timesteps, gradient_steps=args.gradient_steps)
-    learner = DQNLearner(env, extractor=args.extractor, seed=args.seed, reward_scale=args.reward_scale, tune_gemms=args.tune_gemms, **hp)
+    learner = DQNLearner(env, extractor=args.extractor, seed=args.seed, reward_scale=args.reward_scale, updates_per_transition=args.updates_per_transition, tune_gemms=True if args.tune_gemms else None, **hp)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     half = {}
@@ -68,7 +69,8 @@ def main():
            "ms_per_vector_step": dt / max(1, learner.n_calls) * 1e3, "gradient_steps": learner.n_updates,
            "second_half_timesteps_per_s": (learner.num_timesteps - half["n"]) / (t1 - half["t"]) if "t" in half and t1 > half["t"] else None,
            "second_half_ms_per_vector_step": (t1 - half["t"]) / max(1, learner.n_calls - half["calls"]) * 1e3 if "t" in half else None,
-           "graph_replay": learner._act_graphs is not None and learner._train_graph is not None, "tune_gemms": bool(args.tune_gemms),
+           "graph_replay": learner._act_graphs is not None and learner._train_graph is not None, "tune_gemms": bool(learner.tune_gemms),
+           "updates_per_transition": learner.updates_per_transition,
            "last_loss": None if learner.last_loss is None else float(learner.last_loss.detach()),
            "learning_rate_now": learner.lr_schedule(learner.progress_remaining()), "epsilon_now": learner.exploration_rate(),
            "replay_slots": learner.ring.capacity, "replay_chunk": learner.ring.L,
