@@ -107,6 +107,7 @@ inline void derive_consts(const UavEnvConfig& c, Consts& k) {
     k.max_tries = c.max_start_tries; k.use_ema = c.use_ema_adr; k.n_grid_choices = c.num_grid_choices;
     k.flags = c.flags;
     for (int i = 0; i < 8; i++) { k.gw[i] = c.grid_choices_w[i]; k.gh[i] = c.grid_choices_h[i]; }
+    k.n_max = c.num_sensors;
     k.inv_small[0] = 0.0;
     for (int i = 1; i <= 64; i++) k.inv_small[i] = 1.0 / (double)i;
 }

@@ -58,6 +58,7 @@ struct Consts {
     double min_start_dist, prox_eta, jain_weight;
     int32_t max_tries, n_grid_choices;
     int32_t gw[8], gh[8];
+    int32_t n_max, pad0;   // the handle's sensor count (no environment has more): lanes >= n_max never hold a sensor; host side only
     double inv_small[65];  // RN(1/k), k = 1..64: divisions by a sensor / winner count go through div_const()
 };
 

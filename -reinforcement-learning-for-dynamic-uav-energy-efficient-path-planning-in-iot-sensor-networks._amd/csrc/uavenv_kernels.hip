@@ -460,6 +460,16 @@ template <int G, typename P> __device__ __forceinline__ void load_sensor(const P
     s.avg = sensor_at<double>(p, kOffAvg, idx);
     s.flags = sensor_at<uint32_t>(p, kOffFlags, idx);
 }
+// The step kernel's form: lanes that hold no sensor in ANY environment of the handle (lane >= the handle's sensor count, known at
+// launch) fetch nothing -- at 50 sensors in a 64-lane group that is 22 % of the state rows' read bytes -- and see the all-zero
+// rows that are there anyway (the init kernel's; nothing ever writes them: store_sensor skips lanes beyond an environment's count).
+template <int G, typename P> __device__ __forceinline__ void load_sensor_live(const P& p, uint32_t idx, Sensor& s, bool lane_in_use) {
+    s.sx = 0.f; s.sy = 0.f; s.b = 0.0; s.gen = 0.0; s.tx = 0.0; s.lost = 0.0; s.avg = 0.0; s.flags = 12u;
+#ifndef UAV_ABL_LOADALL
+    if (lane_in_use)
+#endif
+        load_sensor<G>(p, idx, s);
+}
 // Write back what the step can have changed: nothing for lanes beyond the environment's sensor count (`live` false:
 // their state never changes), `tx` only if some lane of the wave collected or reset (bit 0 of `dirty`, set where the
 // step touches it), `lost` only if some buffer overflowed or reset (bit 1).  Cuts the write traffic by about a third.
@@ -851,6 +861,22 @@ __device__ __forceinline__ int random_action(uint32_t w3) { return (int)(((uint6
 // launch uses "(word & 7) == 4" to spread the collect steps over the SIMDs.  0 = no information.
 __device__ __forceinline__ uint32_t hint_tag(uint32_t episode, uint32_t step) { return 8u | ((step & 0xFFFFu) << 4) | (episode << 20); }
 
+// Timing-only probes of DESIGN.md section 8's "wave-uniform work of the 16 environments of a workgroup packed into one wave" (tools/exp.sh):
+//   -DUAV_EXP_UNIFORM_SKIP  only the first wavefront of a workgroup executes the two largest wave-uniform blocks (the move and the
+//                           record epilogue; the others keep stale values): an UPPER bound of what packing them could save;
+//   -DUAV_EXP_BARRIERS      two workgroup barriers where the packed form would exchange through LDS: its COST side.
+// Neither build computes a correct step.
+#ifdef UAV_EXP_UNIFORM_SKIP
+#define UAV_UNIFORM_LEADER (G != 64 || (threadIdx.x >> 6) == 0)
+#else
+#define UAV_UNIFORM_LEADER true
+#endif
+#ifdef UAV_EXP_BARRIERS
+#define UAV_EXP_BARRIER() __builtin_amdgcn_s_barrier()
+#else
+#define UAV_EXP_BARRIER() do { } while (0)
+#endif
+
 template <int G, bool kLean, bool kRegs = false, typename RecPtr = UavEnvRecord*, typename CT = Consts, typename P = Ptrs, typename A = StepArgs>
 __device__ __forceinline__ void step_once(const CT& c, const P& p, const A& a, uint32_t env, bool in_batch,
                                           RecPtr rec, UavEnvRecord* rec_out, Sensor& s, bool& wrote_pos, bool& live, uint32_t& dirty, uint32_t& status_or,
@@ -934,7 +960,7 @@ __device__ __forceinline__ void step_once(const CT& c, const P& p, const A& a, u
     // Written branch-free (bitwise &, selects) on purpose: ROCm 7.2's gfx950 backend mis-compiled the
     // natural `ok = a && b && c && d; if (ok) {..} else {..}` form here (the e_move / r_move selects were
     // sunk into the `0 <= nx` block only; caught by the parity tests).
-    {
+    if (UAV_UNIFORM_LEADER) {
         const double battery_before = e.battery;
         const float dxm = action == 2 ? -1.0f : (action == 3 ? 1.0f : 0.0f);
         const float dym = action == 0 ? 1.0f : (action == 1 ? -1.0f : 0.0f);
@@ -954,6 +980,7 @@ __device__ __forceinline__ void step_once(const CT& c, const P& p, const A& a, u
         bh_inc = (is_m & !ok) ? 1 : 0;
         reward = is_m ? rw : 0.0;
     }
+    UAV_EXP_BARRIER();
 
     // One deterministic path-loss evaluation per sensor and step: a collect step does not move the
     // UAV, so the five RSSI samples of a step (zA,zB,zC at the pre-action position, zD,zE at the
@@ -1175,6 +1202,8 @@ __device__ __forceinline__ void step_once(const CT& c, const P& p, const A& a, u
         for (int i = 12; i < 32; i++) u.w[i] = __builtin_amdgcn_readfirstlane(u.w[i]);
         r = u.r;
     }
+    UAV_EXP_BARRIER();
+    if (UAV_UNIFORM_LEADER) {
     r.battery = e.battery; r.uav_x = e.ux; r.uav_y = e.uy; r.current_step = e.step;
     r.episode = e.episode; r.env_index = e.env_index; r.num_sensors = e.n; r.grid_w = e.gw; r.grid_h = e.gh;
     r.inv_grid_w = e.inv_w; r.inv_grid_h = e.inv_h;
@@ -1186,6 +1215,7 @@ __device__ __forceinline__ void step_once(const CT& c, const P& p, const A& a, u
     r.last_step_bytes = (is_m | is_c) ? bytes_step : r.last_step_bytes;           // :463, :607
     r.capture_triggers += captures;
     r.collisions_total += collisions;
+    }
 
     // ---- DomainRandEnv.step extras (dqn.py:415-444) ---------------------------------------------
     if (UAV_FLAGS(c) & UAVENV_FLAG_PROX_SHAPING) {
@@ -1311,7 +1341,7 @@ __global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kerne
         // The first seven arguments repeat fields of the two structs: they are the pointers the first loads of a wave
         // need, and as leading scalar arguments they arrive PRELOADED in SGPRs with the wave launch (gfx950 kernarg
         // preload, -mllvm -amdgpu-kernarg-preload-count=8 in build.py: 16 SGPRs, the maximum) instead of behind a kernarg-segment
-        // round trip.  launch_word = num_envs | grid blocks << 32 | balance << 63 (gridDim.x itself would be a load from the hidden
+        // round trip.  launch_word = num_envs | grid blocks << 32 | the handle's sensor count << 56 | balance << 63 (gridDim.x itself would be a load from the hidden
         // arguments in front of everything else); seed = the Philox key.
         const Consts* cptr, char* sensor_base, uint64_t lanes, UavEnvRecord* rec_base, const uint32_t* hint_in,
         const int32_t* actions, uint64_t launch_word, uint64_t seed, Ptrs p_in, StepArgs a_in) {
@@ -1334,7 +1364,8 @@ __global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kerne
                  : "=&s"(pf0), "=&s"(pf1), "=&s"(pf2), "=&s"(pf3) : "s"(ka));
     const int32_t num_envs = (int32_t)(uint32_t)launch_word;
     const bool balance = (launch_word >> 63) != 0ull;
-    const uint32_t grid_blocks = (uint32_t)(launch_word >> 32) & 0x7FFFFFFFu;
+    const uint32_t grid_blocks = (uint32_t)(launch_word >> 32) & 0x00FFFFFFu;
+    const int max_sensors = (int)((launch_word >> 56) & 0x7Fu);                // the handle's sensor count (1..64)
     decltype(auto) c = ConstsSel<kDefC>::make(*(const __attribute__((address_space(4))) Consts*)(cptr), seed);
 #ifdef UAVENV_STAMPS
     const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
@@ -1430,7 +1461,7 @@ __global__ __launch_bounds__(kWaves * 64, (G == 64 ? 4 : 2)) void uav_step_kerne
     const uint32_t idx = env * G + gl;
     const bool in_batch = env < (uint32_t)num_envs;
     Sensor s;
-    load_sensor<G>(sb, idx, s);
+    load_sensor_live<G>(sb, idx, s, gl < max_sensors);
     asm volatile("s_waitcnt lgkmcnt(0)" :: "s"(pf0), "s"(pf1), "s"(pf2), "s"(pf3));    // (drains the kernarg prefetch above)
     int wt_word = 0;                                  // StepArgs::write_through, handed back by step_once (it loads the output block)
     bool wrote_pos = false, live = false;
@@ -1640,7 +1671,8 @@ hipError_t launch_step(int Gw, int padded_envs, const Consts& c, const Consts* d
     const bool big = step_uses_big_workgroups(Gw, padded_envs);
     const int wg_waves = big ? kBlockThreads / 64 : kSmallBlockThreads / 64;
     dim3 block(wg_waves * 64), grid((unsigned)(waves / wg_waves));
-    const uint64_t be = ((uint64_t)(a.balance != 0) << 63) | ((uint64_t)grid.x << 32) | (uint64_t)(uint32_t)a.num_envs;
+    const uint64_t be = ((uint64_t)(a.balance != 0) << 63) | ((uint64_t)(c.n_max & 0x7F) << 56) | ((uint64_t)(grid.x & 0x00FFFFFFu) << 32) |
+                        (uint64_t)(uint32_t)a.num_envs;
 #define UAV_STEP_LAUNCH(LEAN, WV, DEFC) uav_step_kernel<G, LEAN, WV, DEFC><<<grid, block, lds_bytes(Gw, c), s>>>( \
         dc, p.sensor_base, p.lanes, p.rec, a.hint_in, a.actions, be, c.seed, p, a)
     if (lean_ok(c, p, a) && default_consts) {       // the reference configuration: constants as instruction literals

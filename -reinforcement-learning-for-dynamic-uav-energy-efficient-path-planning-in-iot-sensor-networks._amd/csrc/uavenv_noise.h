@@ -113,6 +113,18 @@ UAV_HD void normal_pair(uint32_t a, uint32_t b, float& z0, float& z1) {
 #ifdef UAV_ABL_NORMAL      // timing-only ablation build
     z0 = (float)(a >> 8) * 0x1p-23f - 1.0f; z1 = (float)(b >> 8) * 0x1p-23f - 1.0f; return;
 #endif
+#if defined(UAV_HW_TRANSCENDENTALS) && defined(__HIP_DEVICE_COMPILE__)
+    // Experiment (tools/exp.sh hwtrans=-DUAV_HW_TRANSCENDENTALS): Box-Muller on the hardware's v_log_f32 / v_sqrt_f32 / v_sin_f32 /
+    // v_cos_f32 (1 ulp-ish, NOT reproducible by the CPU oracle: the keyed parity tests would have to consume device-dumped tapes).
+    // Measured worth: DESIGN.md section 4 (round 3).
+    {
+        const float u1h = (float)((a >> 8) + 1u) * 0x1p-24f;
+        const float rh = __builtin_amdgcn_sqrtf(-1.38629436f * __builtin_amdgcn_logf(u1h));     // -2 ln u = -2 ln 2 * log2 u
+        const float turns = (float)(b >> 8) * 0x1p-24f;                                          // v_sin / v_cos take revolutions
+        z0 = rh * __builtin_amdgcn_cosf(turns); z1 = rh * __builtin_amdgcn_sinf(turns);
+        return;
+    }
+#endif
     uint32_t k = (a >> 8) + 1u;
     float u1 = (float)k * 0x1p-24f;
     uint32_t bits = float_to_bits(u1);
