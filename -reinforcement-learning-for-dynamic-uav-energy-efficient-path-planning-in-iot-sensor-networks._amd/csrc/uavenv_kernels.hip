@@ -460,12 +460,13 @@ template <int G, typename P> __device__ __forceinline__ void load_sensor(const P
     s.avg = sensor_at<double>(p, kOffAvg, idx);
     s.flags = sensor_at<uint32_t>(p, kOffFlags, idx);
 }
-// The step kernel's form: lanes that hold no sensor in ANY environment of the handle (lane >= the handle's sensor count, known at
-// launch) fetch nothing -- at 50 sensors in a 64-lane group that is 22 % of the state rows' read bytes -- and see the all-zero
-// rows that are there anyway (the init kernel's; nothing ever writes them: store_sensor skips lanes beyond an environment's count).
+// Tried in round 3 and measured SLOWER (tools/exp.sh, -DUAV_EXP_MASK_LOADS): lanes that hold no sensor in any environment of the
+// handle (lane >= the handle's sensor count, which the launch word carries) fetching nothing -- 22 % of the state rows' read bytes
+// at 50 sensors in a 64-lane group.  7.63 vs 7.39 us per launch at 4096 x 50: the launch is not bound by those bytes, and the
+// compare + exec mask in front of the loads delays every wave's first memory request.
 template <int G, typename P> __device__ __forceinline__ void load_sensor_live(const P& p, uint32_t idx, Sensor& s, bool lane_in_use) {
+#ifdef UAV_EXP_MASK_LOADS
     s.sx = 0.f; s.sy = 0.f; s.b = 0.0; s.gen = 0.0; s.tx = 0.0; s.lost = 0.0; s.avg = 0.0; s.flags = 12u;
-#ifndef UAV_ABL_LOADALL
     if (lane_in_use)
 #endif
         load_sensor<G>(p, idx, s);
