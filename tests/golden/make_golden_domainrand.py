@@ -25,7 +25,8 @@ fixture with NO tape at all -- plain `seed`, the fixture's actions, in-kernel Ph
 Recorded per case: meta (fixed_n, curriculum stage, seed, env_index, BASE_ENV_CONFIG overrides), actions; per step the padded
 observation (the terminal one on a truncating step), the returned (shaped) reward, truncated, SF per sensor; per episode the
 grid, the far start, the layout, the reset observation; per FINISHED episode every value of `last_episode_stats`
-(dqn.py:316-331) exactly as the real class computed it.
+(dqn.py:316-331) exactly as the real class computed it; per step the `info` dict the real step() returned (the 17 keys of
+uav_env.py:676-700).
 
 The C oracle runs alongside (keyed entry points) and every value is compared as it is recorded; a seed whose trajectory
 hits the 1-ulp platform fuzz of the reference's float32 log10 / pow (oracle/uavenv_oracle.h) is skipped and listed.
@@ -49,6 +50,10 @@ DQN = os.path.join(R.REF_SRC, "agents", "dqn", "dqn.py")
 BANNER_BEGIN = "# ==================== DOMAIN DISTRIBUTION"
 BANNER_END = "# ==================== GREEDY BENCHMARK"
 FLAGS_ALL = O.FLAG_RANDOM_LAYOUT | O.FLAG_FAR_START | O.FLAG_PROX_SHAPING | O.FLAG_JAIN_BONUS
+# the reference's _get_info() (uav_env.py:676-700): the 14 scalar keys in this order, + uav_position, + sensor_collection_ratios
+INFO_KEYS = ["battery", "battery_percent", "sensors_collected", "current_step", "total_reward", "total_data_collected",
+             "coverage_percentage", "is_alive", "max_urgency", "avg_urgency", "high_urgency_sensors", "capture_effect_triggers",
+             "boundary_hits", "edge_steps", "last_step_bytes_collected"]
 STAT_KEYS = ["total_generated", "total_collected", "total_lost", "battery_remaining", "ndr", "fairness_std", "jains_index",
              "data_efficiency", "bytes_per_wh"]
 
@@ -311,6 +316,7 @@ CASES = [
 def record(case, seed, env_index):
     n = case["n"]
     obs, rew, trunc, sfs, acts = [], [], [], [], []
+    info_s, info_p, info_r = [], [], []
     ep_grid, ep_start, ep_pos, ep_reset_obs, ep_stats = [], [], [], [], []
 
     def fail(where, what, rs=None, os_=None):
@@ -345,8 +351,10 @@ def record(case, seed, env_index):
             return fail("first reset", bad)
         for k in range(case["steps"]):
             a = choose_action(ref.state(), k, seed)
-            ro, rr, rte, rtr, _ = ref.step(a)
-            assert rte is False
+            ro, rr, rte, rtr, rinfo = ref.step(a)
+            assert rte is False and len(rinfo) == len(INFO_KEYS) + 2
+            info_s.append([float(rinfo[key]) for key in INFO_KEYS]); info_p.append(rinfo["uav_position"])
+            info_r.append(rinfo["sensor_collection_ratios"])
             oo, orr, otr = orc.step_keyed(a)
             rs, os_ = ref.state(), orc.state()
             bad = compare_states(rs, os_)
@@ -371,7 +379,9 @@ def record(case, seed, env_index):
         meta=np.array(json.dumps(dict(name=case["name"], n=n, stage=case["stage"], grids=[list(g) for g in grids],
                                       steps=case["steps"], seed=seed, env_index=env_index, base=case["base"],
                                       stat_keys=STAT_KEYS + ["grid_w", "grid_h", "num_sensors", "length",
-                                                             "first_full_coverage_step"]))),
+                                                             "first_full_coverage_step"], info_keys=INFO_KEYS))),
+        info_scalars=np.array(info_s, np.float64), info_uav_position=np.array(info_p, np.float32),
+        info_sensor_collection_ratios=np.array(info_r, np.float64),
         actions=np.array(acts, np.int8), obs=np.array(obs, np.float32), reward=np.array(rew, np.float64),
         truncated=np.array(trunc, np.uint8), sf=np.array(sfs, np.int8),
         ep_grid=np.array(ep_grid, np.int32), ep_start=np.array(ep_start, np.float32), ep_pos=np.array(ep_pos, np.float32),

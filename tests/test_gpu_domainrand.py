@@ -38,6 +38,21 @@ def _check_stats(got, row, keys, where):
     assert got["time_to_coverage"] is None          # dqn.py:302 clears the attribute before :330 reads it
 
 
+def _check_info(info, fx, s, where):
+    """The 17 keys of the reference's _get_info() (uav_env.py:676-700) as the REAL step() returned them at step s."""
+    keys = fx["meta"]["info_keys"]
+    want = dict(zip(keys, fx["info_scalars"][s]))
+    for k in ("sensors_collected", "current_step", "high_urgency_sensors", "capture_effect_triggers", "boundary_hits", "edge_steps"):
+        assert info[k] == int(want[k]), (where, k, info[k], want[k])
+    assert bool(info["is_alive"]) == bool(want["is_alive"]), where
+    for k in ("battery", "battery_percent", "total_reward", "total_data_collected", "coverage_percentage", "last_step_bytes_collected"):
+        assert _rel(float(info[k]), want[k]) <= RTOL, (where, k, info[k], want[k])
+    for k in ("max_urgency", "avg_urgency"):                      # float32 AoI urgencies (uav_env.py:386-394)
+        assert abs(float(info[k]) - want[k]) <= 1e-6 * max(1.0, abs(want[k])), (where, k, info[k], want[k])
+    assert np.array_equal(np.asarray(info["uav_position"], np.float32), fx["info_uav_position"][s]), where
+    assert np.allclose(info["sensor_collection_ratios"], fx["info_sensor_collection_ratios"][s], rtol=1e-12, atol=1e-15), where
+
+
 def _kernel_stats_as_dict(st, max_battery):
     """UavEnvEpisodeStats (include/uavenv.h) -> the dqn.py:316-331 keys, the way vec_env.py derives them."""
     tg, tc = float(st["total_generated"]), float(st["total_collected"])
@@ -129,6 +144,8 @@ def test_gym_domainrand_env_matches_the_real_class(name):
         obs, r, term, trunc, info = env.step(int(a))
         assert term is False and trunc == bool(fx["truncated"][s])
         assert np.max(np.abs(obs - fx["obs"][s])) <= OBS_ATOL and _rel(r, fx["reward"][s]) <= RTOL, (name, s)
+        assert len(info) == 17
+        _check_info(info, fx, s, (name, s))
         if trunc:
             obs, _ = env.reset()
             _check_stats(env.last_episode_stats, fx["ep_stats"][ep], meta["stat_keys"], (name, ep))
@@ -170,6 +187,7 @@ def test_vec_env_last_episode_stats_match_the_real_class(name):
             assert _rel(info["total_data_collected"], want["total_collected"]) <= RTOL
             assert _rel(info["battery"], want["battery_remaining"]) <= RTOL
             assert _rel(info["coverage_percentage"], want["ndr"]) <= RTOL
+            _check_info(info, fx, s, (name, s))                       # all 17 keys of the TERMINAL step, from the terminal snapshot
             ep += 1
             ret = 0.0
             assert np.array_equal(obs[k], fx["ep_reset_obs"][ep])
