@@ -10,7 +10,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libuavenv_hip.so")
-SOURCES = ["uavenv_kernels.hip", "uavenv_capi.hip", "uavenv_attention.hip", "uavenv_replay.hip"]
+SOURCES = ["uavenv_kernels.hip", "uavenv_capi.hip", "uavenv_attention.hip", "uavenv_replay.hip", "uavenv_learner.hip"]
 HEADERS = ["uavenv_internal.h", "uavenv_noise.h", "uavenv_derive.h", "uavenv_default_consts.inc", "gen_default_consts.cpp",
            os.path.join("..", "..", "include", "uavenv.h")]
 GENERATED = os.path.join(CSRC, "uavenv_default_consts.inc")

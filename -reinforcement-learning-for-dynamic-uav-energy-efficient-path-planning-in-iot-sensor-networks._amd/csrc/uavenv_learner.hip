@@ -1,0 +1,248 @@
+// uavenv_learner.hip -- the DQN update of the reference's MLP policy as a handful of HIP launches.
+//
+// What it replaces: one `DQN.train()` gradient step of stable-baselines3 as the reference configures it
+// (agents/dqn/dqn.py:1077-1099: MlpPolicy net_arch [512, 512, 256], batch_size 256, gamma 0.99, Adam, max_grad_norm 10) --
+// forward of the online and the target network, smooth-L1 TD loss, backward, gradient clipping, Adam.  In PyTorch that is
+// ~60 launches of which a dozen are float32 library GEMMs with a batch of 256 rows: 14-29 us each, because a 256 x 512 output
+// is 16 macro tiles for 256 CUs (profiles/r02p_learner_kernel_stats.md); 337 us per update when the GEMM choices are tuned.
+// The arithmetic is 1.45 GFLOP -- 9 us at the f32 MFMA rate -- so the update is latency- and occupancy-bound, not compute-bound.
+//
+// Here: ONE small-batch GEMM kernel on v_mfma_f32_16x16x4_f32 for all three products of a Linear layer
+//     forward   Y[b][n]  += sum_k X[b][k] W[n][k]      (both operands contiguous along k)
+//     input     dX[b][k] += sum_n dZ[b][n] W[n][k]
+//     weight    dW[n][k] += sum_b dZ[b][n] X[b][k]     (+ bias gradient = row sums of the transposed operand)
+// a wavefront owns a 16 x 64 output tile of a K-SLICE (split-K: 1000-2000 wavefronts per product, every CU busy), fragments come
+// straight from global memory (everything is L2 resident: 2.8 MB of weights, < 1 MB of activations), partial tiles are added
+// with hardware float atomics into zeroed outputs.  ReLU is never a pass of its own: a layer stores its PRE-activation and the
+// consumer applies max(., 0) -- or, backward, the (z > 0) mask -- while loading the operand.  Around it: the TD loss with its
+// gradient in one workgroup, the global gradient norm, and clip + Adam over ONE flat parameter buffer.
+// fp32 throughout; parity is against torch autograd + torch.optim.Adam on the same batch (tests/test_gpu_mlp_update.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/uavenv.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    const float* bias;        // UAVENV_GEMM_BIAS: added once (by the first K slice) to every row
+    const float* a_mask;      // UAVENV_GEMM_A_MASK: same indexing as A; A is used where a_mask > 0, else 0 (ReLU backward)
+    float* row_sum;           // UAVENV_GEMM_ROWSUM: row_sum[m] += sum_k A(m, k) after the transform (bias gradient)
+    int32_t M, N, K;
+    int64_t a_sm, a_sk, b_sk, b_sn, ldc;      // element (m, k) of A at A[m * a_sm + k * a_sk]; (k, n) of B at B[k * b_sk + n * b_sn]
+    int32_t flags, splits;
+};
+
+__device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// four consecutive-k elements of an operand: `p` points at element (row, k); contiguous along k (KC) or strided by `sk`
+template <bool KC>
+__device__ __forceinline__ f32x4 load_k4(const float* p, int64_t sk, int k, int K, bool row_ok) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (!row_ok) return v;
+    if (KC) {
+        if (k + 3 < K && aligned16(p)) return *reinterpret_cast<const f32x4*>(p);
+        if (k < K) v.x = p[0];
+        if (k + 1 < K) v.y = p[1];
+        if (k + 2 < K) v.z = p[2];
+        if (k + 3 < K) v.w = p[3];
+    } else {
+        if (k < K) v.x = p[0];
+        if (k + 1 < K) v.y = p[sk];
+        if (k + 2 < K) v.z = p[2 * sk];
+        if (k + 3 < K) v.w = p[3 * sk];
+    }
+    return v;
+}
+__device__ __forceinline__ f32x4 relu4(f32x4 v) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); return v; }
+
+// C[M x N] += A[M x K] . B[K x N]; M, N and K are arbitrary (guards on the tails).  One wavefront: rows
+// 16 * im .., columns 64 * in .., k blocks [kb0, kb1) of 16.  MFMA operand map: lane l = (row / column r = l & 15, k group g = l >> 4)
+// holds k = 16 * kb + 4 * g + t in step t -- any assignment works as long as A and B use the same one.
+template <bool AK, bool BK>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+    const int lane = threadIdx.x & 63;
+    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int mt = (g.M + 15) >> 4, nt = (g.N + 63) >> 6;
+    if (task >= mt * nt * g.splits) return;
+    const int split = task / (mt * nt), rem = task - split * (mt * nt);
+    const int im = rem % mt, in = rem / mt;
+    const int kblocks = (g.K + 15) >> 4, per = (kblocks + g.splits - 1) / g.splits;
+    const int kb0 = split * per, kb1 = min(kblocks, kb0 + per);
+    const int r = lane & 15, gq = lane >> 4;
+    const int m = im * 16 + r;
+    const bool a_relu = (g.flags & UAVENV_GEMM_A_RELU) != 0, a_mask = (g.flags & UAVENV_GEMM_A_MASK) != 0;
+    const bool b_relu = (g.flags & UAVENV_GEMM_B_RELU) != 0;
+    const bool want_rowsum = (g.flags & UAVENV_GEMM_ROWSUM) != 0 && in == 0;
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float rowsum = 0.f;
+    for (int kb = kb0; kb < kb1; kb++) {
+        const int k = kb * 16 + 4 * gq;
+        const int64_t a_off = (int64_t)m * g.a_sm + (int64_t)k * g.a_sk;
+        f32x4 a = load_k4<AK>(g.A + a_off, g.a_sk, k, g.K, m < g.M);
+        if (a_relu) a = relu4(a);
+        if (a_mask) {
+            const f32x4 z = load_k4<AK>(g.a_mask + a_off, g.a_sk, k, g.K, m < g.M);
+            a.x = z.x > 0.f ? a.x : 0.f; a.y = z.y > 0.f ? a.y : 0.f; a.z = z.z > 0.f ? a.z : 0.f; a.w = z.w > 0.f ? a.w : 0.f;
+        }
+        if (want_rowsum) rowsum += (a.x + a.y) + (a.z + a.w);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int n = in * 64 + 16 * j + r;
+            f32x4 b = load_k4<BK>(g.B + (int64_t)k * g.b_sk + (int64_t)n * g.b_sn, g.b_sk, k, g.K, n < g.N);
+            if (b_relu) b = relu4(b);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[j], 0, 0, 0);
+        }
+    }
+    if (kb1 <= kb0) return;
+    // result tile: lane holds column r, rows 4 * gq + i
+    const bool add_bias = (g.flags & UAVENV_GEMM_BIAS) != 0 && split == 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int n = in * 64 + 16 * j + r;
+        if (n >= g.N) continue;
+        const float bv = add_bias ? g.bias[n] : 0.f;
+        const float v[4] = {acc[j].x, acc[j].y, acc[j].z, acc[j].w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int mm = im * 16 + 4 * gq + i;
+            if (mm < g.M) unsafeAtomicAdd(g.C + (int64_t)mm * g.ldc + n, v[i] + bv);
+        }
+    }
+    if (want_rowsum) {                                        // the four k groups of a row sit 16 lanes apart
+        rowsum += __shfl_xor(rowsum, 16);
+        rowsum += __shfl_xor(rowsum, 32);
+        if (gq == 0 && m < g.M) unsafeAtomicAdd(g.row_sum + m, rowsum);
+    }
+}
+
+// SB3 DQN.train's loss on one batch and its gradient w.r.t. the online Q-values, one workgroup:
+//   target = reward_scale * r + gamma * max_a' Q_target(s', a')      (no (1 - done): every episode end is a truncation)
+//   loss = sum_b w_b * smooth_l1(Q(s_b, a_b) - target_b) / max(sum_b w_b, 1),  w = valid
+//   dq[b][a_b] = w_b / max(sum w, 1) * clamp(Q - target, -1, 1), zero elsewhere.
+// Also advances the optimiser's step count and writes Adam's two bias corrections for it.
+__global__ __launch_bounds__(1024) void td_loss_kernel(const float* __restrict__ q, const float* __restrict__ q_next, const int64_t* __restrict__ action,
+                                                     const float* __restrict__ reward, const uint8_t* __restrict__ valid, int32_t batch,
+                                                     int32_t n_actions, float gamma, float reward_scale, float beta1, float beta2,
+                                                     float* __restrict__ dq, float* __restrict__ scalars) {
+    __shared__ float s_w[16], s_l[16];
+    const int b = threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float w = 0.f, d = 0.f, l = 0.f;
+    int a = 0;
+    if (b < batch) {
+        float mx = q_next[(size_t)b * n_actions];
+        for (int j = 1; j < n_actions; j++) mx = fmaxf(mx, q_next[(size_t)b * n_actions + j]);
+        a = (int)action[b];
+        d = q[(size_t)b * n_actions + a] - (reward_scale * reward[b] + gamma * mx);
+        w = valid[b] ? 1.f : 0.f;
+        const float ad = fabsf(d);
+        l = w * (ad < 1.f ? 0.5f * d * d : ad - 0.5f);
+    }
+    float ws = w, ls = l;
+    for (int o = 32; o > 0; o >>= 1) { ws += __shfl_xor(ws, o); ls += __shfl_xor(ls, o); }
+    if (lane == 0) { s_w[wv] = ws; s_l[wv] = ls; }
+    __syncthreads();
+    float wt = 0.f, lt = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); i++) { wt += s_w[i]; lt += s_l[i]; }
+    const float inv = 1.f / fmaxf(wt, 1.f);
+    if (b < batch) {
+        for (int j = 0; j < n_actions; j++) dq[(size_t)b * n_actions + j] = 0.f;
+        dq[(size_t)b * n_actions + a] = w * inv * fminf(fmaxf(d, -1.f), 1.f);
+    }
+    if (threadIdx.x == 0) {
+        scalars[UAVENV_UPD_LOSS] = lt * inv;
+        scalars[UAVENV_UPD_NORM2] = 0.f;                       // uavenv_grad_sum_squares adds into it
+        const float t = scalars[UAVENV_UPD_STEP] + 1.f;
+        scalars[UAVENV_UPD_STEP] = t;
+        scalars[UAVENV_UPD_BC1] = 1.f - powf(beta1, t);
+        scalars[UAVENV_UPD_BC2] = 1.f - powf(beta2, t);
+    }
+}
+
+__global__ __launch_bounds__(256) void sum_squares_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += g[i] * g[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(out, s);
+}
+
+// torch.nn.utils.clip_grad_norm_(max_norm) followed by torch.optim.Adam.step() (no weight decay, no amsgrad) over flat buffers
+__global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2,
+                                                      int64_t n, const float* __restrict__ scalars, float max_norm, float beta1, float beta2, float eps) {
+    const float norm = sqrtf(scalars[UAVENV_UPD_NORM2]);
+    const float coef = fminf(max_norm / (norm + 1e-6f), 1.0f);
+    const float lr = scalars[UAVENV_UPD_LR], bc1 = scalars[UAVENV_UPD_BC1], bc2s = sqrtf(scalars[UAVENV_UPD_BC2]);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * coef;
+        const float a = beta1 * m1[i] + (1.f - beta1) * gi;
+        const float v = beta2 * m2[i] + (1.f - beta2) * gi * gi;
+        m1[i] = a; m2[i] = v;
+        p[i] -= (lr / bc1) * (a / (sqrtf(v) / bc2s + eps));
+    }
+}
+
+}  // namespace
+
+// replaces: the three matrix products of torch.nn.Linear's forward / backward at DQN batch sizes (dqn.py:1086 batch_size 256).
+// C[M x N] += A . B with A(m, k) = A_dev[m * a_sm + k * a_sk], B(k, n) = B_dev[k * b_sk + n * b_sn]; C row-major with ldc, and it
+// must hold the addend already (zeros for a plain product: the K slices are accumulated with float atomics).
+// One of a_sm / a_sk (b_sk / b_sn) must be 1; flags UAVENV_GEMM_*; splits >= 1 = number of K slices.
+extern "C" int uavenv_gemm_f32(const float* a_dev, const float* b_dev, float* c_dev, const float* bias_dev, const float* a_mask_dev,
+                               float* row_sum_dev, int32_t m, int32_t n, int32_t k, int64_t a_sm, int64_t a_sk, int64_t b_sk, int64_t b_sn,
+                               int64_t ldc, int32_t flags, int32_t splits, void* stream) {
+    if (!a_dev || !b_dev || !c_dev || m < 1 || n < 1 || k < 1 || splits < 1 || ldc < n) return UAVENV_E_INVALID;
+    if ((a_sm != 1 && a_sk != 1) || (b_sk != 1 && b_sn != 1)) return UAVENV_E_INVALID;
+    if (((flags & UAVENV_GEMM_BIAS) && !bias_dev) || ((flags & UAVENV_GEMM_A_MASK) && !a_mask_dev) || ((flags & UAVENV_GEMM_ROWSUM) && !row_sum_dev))
+        return UAVENV_E_INVALID;
+    GemmArgs g{a_dev, b_dev, c_dev, bias_dev, a_mask_dev, row_sum_dev, m, n, k, a_sm, a_sk, b_sk, b_sn, ldc, flags, splits};
+    const int kblocks = (k + 15) / 16;
+    if (g.splits > kblocks) g.splits = kblocks;
+    const long tasks = (long)((m + 15) / 16) * ((n + 63) / 64) * g.splits;
+    const dim3 grid((unsigned)((tasks + 3) / 4)), block(256);
+    const bool ak = a_sk == 1, bk = b_sk == 1;
+    hipStream_t s = (hipStream_t)stream;
+    if (ak && bk) gemm_f32_kernel<true, true><<<grid, block, 0, s>>>(g);
+    else if (ak) gemm_f32_kernel<true, false><<<grid, block, 0, s>>>(g);
+    else if (bk) gemm_f32_kernel<false, true><<<grid, block, 0, s>>>(g);
+    else gemm_f32_kernel<false, false><<<grid, block, 0, s>>>(g);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_E_HIP;
+}
+
+// replaces: the loss of SB3's DQN.train (smooth-L1 TD error, dqn.py:1087 gamma) and its backward into the Q-values; scalars_dev
+// float[UAVENV_UPD_COUNT]: receives the loss, holds / advances the optimiser step count and Adam's bias corrections.  batch <= 1024.
+extern "C" int uavenv_td_loss(const float* q_dev, const float* q_next_dev, const int64_t* action_dev, const float* reward_dev,
+                              const uint8_t* valid_dev, int32_t batch, int32_t n_actions, float gamma, float reward_scale, float beta1,
+                              float beta2, float* dq_dev, float* scalars_dev, void* stream) {
+    if (!q_dev || !q_next_dev || !action_dev || !reward_dev || !valid_dev || !dq_dev || !scalars_dev || batch < 1 || batch > 1024 || n_actions < 1)
+        return UAVENV_E_INVALID;
+    const int threads = ((batch + 63) / 64) * 64;
+    td_loss_kernel<<<dim3(1), dim3(threads), 0, (hipStream_t)stream>>>(q_dev, q_next_dev, action_dev, reward_dev, valid_dev, batch, n_actions,
+                                                                     gamma, reward_scale, beta1, beta2, dq_dev, scalars_dev);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_E_HIP;
+}
+
+// replaces: clip_grad_norm_(parameters, max_norm) + Adam.step() of SB3's DQN.train over ONE flat buffer of n parameters
+// (the caller keeps the module's parameters as views of it).  uavenv_grad_sum_squares adds sum g^2 to scalars[UAVENV_UPD_NORM2]
+// (uavenv_td_loss zeroes it); uavenv_clip_adam reads it, the learning rate scalars[UAVENV_UPD_LR] and the bias corrections uavenv_td_loss wrote.
+extern "C" int uavenv_grad_sum_squares(const float* grad_dev, int64_t n, float* scalars_dev, void* stream) {
+    if (!grad_dev || !scalars_dev || n < 1) return UAVENV_E_INVALID;
+    const unsigned blocks = (unsigned)((n + 256 * 8 - 1) / (256 * 8) < 1024 ? (n + 256 * 8 - 1) / (256 * 8) : 1024);
+    sum_squares_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(grad_dev, n, scalars_dev + UAVENV_UPD_NORM2);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_E_HIP;
+}
+extern "C" int uavenv_clip_adam(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n,
+                                const float* scalars_dev, float max_norm, float beta1, float beta2, float eps, void* stream) {
+    if (!param_dev || !grad_dev || !exp_avg_dev || !exp_avg_sq_dev || !scalars_dev || n < 1) return UAVENV_E_INVALID;
+    const unsigned blocks = (unsigned)((n + 256 * 4 - 1) / (256 * 4) < 2048 ? (n + 256 * 4 - 1) / (256 * 4) : 2048);
+    clip_adam_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(param_dev, grad_dev, exp_avg_dev, exp_avg_sq_dev, n, scalars_dev,
+                                                                        max_norm, beta1, beta2, eps);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_E_HIP;
+}

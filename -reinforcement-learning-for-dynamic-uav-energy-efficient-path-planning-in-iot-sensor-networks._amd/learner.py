@@ -149,7 +149,7 @@ class DQNLearner:
                  target_update_interval=5_000, train_freq=4, gradient_steps=1, net_arch=(512, 512, 256), n_stack=4,
                  total_timesteps=3_000_000, max_grad_norm=10.0, extractor="mlp", shared_exploration_coin=False, seed=0,
                  chunk_len=None, reward_scale=1.0, use_graphs=None, tune_gemms=None, frame_stack_cls=FrameStack,
-                 updates_per_transition=None):
+                 updates_per_transition=None, fused_update=None):
         """reward_scale (not an SB3 / reference option; default 1.0 = theirs): the environment's rewards reach 1e4-1e5 per
         step (+5000 per new sensor, 100 x bytes x urgency), which a smooth-L1 loss follows at one unit of gradient per
         sample -- the reference spends 750 k gradient steps on it.  Short runs (the tests) scale the reward in the loss."""
@@ -184,10 +184,24 @@ class DQNLearner:
         on_gpu = self.dev.type == "cuda"
         self.opt = torch.optim.Adam(self.q.parameters(), lr=torch.tensor(self.lr_schedule(1.0), device=self.dev) if on_gpu
                                     else self.lr_schedule(1.0), capturable=on_gpu, fused=on_gpu or None)
+        # fused_update (default: on for the MLP policy on a GPU): the gradient step runs in the library's own kernels
+        # (mlp_update.py / csrc/uavenv_learner.hip: small-batch MFMA GEMMs, TD loss, clip + Adam over one flat buffer, ~20
+        # launches) instead of torch autograd + torch.optim.Adam (~60 launches, a dozen of them 256-row library GEMMs that use
+        # 16 of 256 CUs); the modules' parameters become views of its flat buffers.  False keeps the PyTorch update (the attention
+        # extractor always does: its backward is PyTorch's).
+        self.fused_update = (on_gpu and extractor == "mlp") if fused_update is None else bool(fused_update)
+        assert not (self.fused_update and extractor != "mlp"), "the fused update covers the MLP policy"
+        self._mlp = None
+        if self.fused_update:
+            from .mlp_update import FusedMLPUpdate
+            self._mlp = FusedMLPUpdate(self.q, self.q_target, self.local_batch, self.gamma, self.max_grad_norm, self.reward_scale,
+                                       lr=self.lr_schedule(1.0))
         self.use_graphs = on_gpu if use_graphs is None else bool(use_graphs)
         self._act_graphs, self._train_graph, self._train_graph_b, self._fused = None, None, None, None
         # one flat buffer for the gradient all-reduce (world > 1)
-        self._flat_grad = torch.zeros(sum(p.numel() for p in self.q.parameters()), device=self.dev) if self.world > 1 else None
+        self._flat_grad = None
+        if self.world > 1:
+            self._flat_grad = self._mlp.grad if self._mlp is not None else torch.zeros(sum(p.numel() for p in self.q.parameters()), device=self.dev)
         # tune_gemms: PyTorch's TunableOp picks the GEMM kernel per shape by timing the candidates the first time a shape is seen
         # (the eager steps before the captures).  The update is a dozen float32 GEMMs of batch 256 whose default kernels leave
         # most of the 256 CUs idle (14-29 us each): 599 -> 348 us per update (1 491 -> 864 us with the attention extractor).
@@ -254,6 +268,9 @@ class DQNLearner:
     _GRAPH_SLOT_LIMIT = 1024            # one graph per ring slot: rings longer than this stay eager
 
     def _set_lr(self, lr):
+        if self._mlp is not None:
+            self._mlp.set_lr(lr)
+            return
         for g in self.opt.param_groups:
             if torch.is_tensor(g["lr"]):
                 g["lr"].fill_(lr)
@@ -333,17 +350,45 @@ class DQNLearner:
         dist.all_reduce(self._flat_grad)
         self._flat_grad.div_(self.world)
 
+    def _backward(self, batch):
+        """Loss and gradients of one batch (several ranks: the gradients end up in the flat buffer the all-reduce works on).
+        Returns the detached loss."""
+        if self._mlp is not None:
+            self._mlp.backward(batch)
+            return self._mlp.loss
+        loss = td_loss(self.q, self.q_target, batch, self.gamma, self.reward_scale)
+        # (one rank inside a capture: fresh gradient tensors from the graph's pool; several ranks: the tensors are part of both graphs)
+        self.opt.zero_grad(set_to_none=self.world == 1)
+        loss.backward()
+        if self.world > 1:
+            self._flatten_grads()
+        # (detached: a loss that keeps its autograd graph keeps the parameters' AccumulateGrad nodes alive, and those remember
+        # the stream they were created on -- a later backward inside a graph capture would run them on that other stream,
+        # which ends the capture with a segmentation fault in the HIP runtime)
+        return loss.detach()
+
+    def _apply(self):
+        """clip_grad_norm_ + Adam on the (averaged) gradients."""
+        if self._mlp is not None:
+            self._mlp.apply()
+            return
+        if self.world > 1:
+            self._unflatten_grads()
+        nn.utils.clip_grad_norm_(self.q.parameters(), self.max_grad_norm)
+        self.opt.step()
+        if self._fused is not None:
+            self._fused.refresh(self.q.features)
+
     def _capture_train_graph(self):
         """One gradient step -- sample, TD loss, backward, clip, Adam -- as a graph.  Captured after eager updates have run
         (optimizer state and library workspaces exist); the ring's sampling window and the learning rate are device scalars
         refreshed before each replay.  With several ranks the step is TWO graphs around the host-issued gradient all-reduce:
-        [sample -> loss -> backward -> flatten] and [unflatten -> clip -> Adam]."""
+        [sample -> loss -> backward (-> flatten)] and [(unflatten ->) clip -> Adam]."""
         self._g_win = (torch.zeros((), dtype=torch.int64, device=self.dev), torch.zeros((), dtype=torch.int64, device=self.dev))
         self._g_loss = torch.zeros((), device=self.dev)
         self._g_index = torch.zeros(4, self.local_batch, dtype=torch.int64, device=self.dev)    # the last replay's draw (tests)
         n, oldest = self.ring.window_state()
         self._g_win[0].fill_(n); self._g_win[1].fill_(oldest)
-        params = list(self.q.parameters())
         self.ring.drain()                                 # (inside the capture sample_stacked must not wait on collectives)
         torch.cuda.synchronize(self.dev)
         g = torch.cuda.CUDAGraph()
@@ -351,27 +396,15 @@ class DQNLearner:
         pool = torch.cuda.graph_pool_handle()
         with torch.cuda.graph(g, pool=pool):
             batch = self.ring.sample_stacked(self.local_batch, self.k, generator=self.gen, window=self._g_win)
-            loss = td_loss(self.q, self.q_target, batch, self.gamma, self.reward_scale)
-            self.opt.zero_grad(set_to_none=self.world == 1)   # (several ranks: the gradient tensors are part of both graphs)
-            loss.backward()
-            self._g_loss.copy_(loss.detach())
+            self._g_loss.copy_(self._backward(batch))
             self._g_index.copy_(torch.stack(batch["index"]))
-            if self.world > 1:
-                self._flatten_grads()
-            else:
-                nn.utils.clip_grad_norm_(params, self.max_grad_norm)
-                self.opt.step()
-                if self._fused is not None:
-                    self._fused.refresh(self.q.features)
+            if self.world == 1:
+                self._apply()
         self._train_graph = g
         if self.world > 1:
             gb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gb, pool=pool):
-                self._unflatten_grads()
-                nn.utils.clip_grad_norm_(params, self.max_grad_norm)
-                self.opt.step()
-                if self._fused is not None:
-                    self._fused.refresh(self.q.features)
+                self._apply()
             self._train_graph_b = gb
         if self.tune_gemms and self._act_graphs is not None:
             self._finish_tuning()                         # every shape of the two loops has been seen
@@ -438,22 +471,12 @@ class DQNLearner:
         loss = None
         for _ in range(steps):
             batch = self.ring.sample_stacked(self.local_batch, self.k, generator=self.gen)
-            loss = td_loss(self.q, self.q_target, batch, self.gamma, self.reward_scale)
-            self.opt.zero_grad(set_to_none=False if self.world > 1 else True)
-            loss.backward()
+            loss = self._backward(batch)
             if self.world > 1:                                     # replicas stay identical: one all-reduce of the flat gradient
-                self._flatten_grads()
                 self._allreduce_grads()
-                self._unflatten_grads()
-            nn.utils.clip_grad_norm_(self.q.parameters(), self.max_grad_norm)
-            self.opt.step()
+            self._apply()
             self.n_updates += 1
-        # (detached: a loss that keeps its autograd graph keeps the parameters' AccumulateGrad nodes alive, and those remember
-        # the stream they were created on -- a later backward inside a graph capture would run them on that other stream,
-        # which ends the capture with a segmentation fault in the HIP runtime)
-        self.last_loss = None if loss is None else loss.detach()
-        if self._fused is not None and loss is not None:
-            self._fused.refresh(self.q.features)
+        self.last_loss = loss
         return self.last_loss
 
     def learn(self, total_timesteps=None, callback=None):

@@ -1,0 +1,169 @@
+"""One DQN gradient step of the reference's MLP policy as ~20 HIP launches (csrc/uavenv_learner.hip) instead of ~60 PyTorch
+ones: what stable-baselines3's `DQN.train()` does per gradient step for `MlpPolicy` with `net_arch=[512, 512, 256]`
+(agents/dqn/dqn.py:1077-1099) -- forward of the online and the target network, smooth-L1 TD loss, backward, clip_grad_norm_,
+Adam -- on one sampled batch.  torch is plumbing here (device buffers, the modules whose parameters become views of one flat
+buffer so that acting keeps using them); every product, the loss, the clipping and the optimiser step run in the library.
+
+Why: the update is 1.45 GFLOP (9 us at the f32 MFMA rate) that PyTorch spends 337 us on -- a dozen library GEMMs whose
+256-row outputs are 16 macro tiles for 256 CUs, and ~45 small launches around them.  At the reference's update ratio (one
+update per 16 transitions) the update is the whole cost of training.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _native as N
+
+
+def _p(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class FusedMLPUpdate:
+    """Owns the flat parameter / gradient / Adam-state buffers of `q` (and `q_target`) and runs updates on sampled batches.
+
+    q, q_target: QNetwork with the Flatten extractor (learner.py): `head` = Linear, ReLU, ..., Linear.  Their parameters are
+    re-pointed to views of `self.flat` / `self.flat_target` (same values), so `q(x)` for acting sees every update.
+    """
+
+    def __init__(self, q, q_target, batch_size, gamma, max_grad_norm, reward_scale=1.0, betas=(0.9, 0.999), eps=1e-8, lr=1e-3):
+        self.L = N.lib()
+        self.q, self.q_target = q, q_target
+        self.layers = [m for m in q.head if isinstance(m, nn.Linear)]
+        self.layers_t = [m for m in q_target.head if isinstance(m, nn.Linear)]
+        assert len(self.layers) >= 1 and all(isinstance(m, (nn.Linear, nn.ReLU)) for m in q.head)
+        self.dev = self.layers[0].weight.device
+        assert self.dev.type == "cuda", "the fused update is a HIP path: there is no CPU form"
+        self.B = int(batch_size)
+        assert self.B % 16 == 0 and self.B <= 1024, "batch_size must be a multiple of 16 (MFMA rows) and <= 1024"
+        self.gamma, self.max_norm, self.reward_scale = float(gamma), float(max_grad_norm), float(reward_scale)
+        self.beta1, self.beta2, self.eps = float(betas[0]), float(betas[1]), float(eps)
+        # ---- one flat buffer per (parameters, target parameters, gradients, Adam moments); the modules' tensors become views
+        sizes = []
+        for m in self.layers:
+            sizes += [m.weight.numel(), m.bias.numel()]
+        self.n_params = sum(sizes)
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        self.flat = torch.empty(self.n_params, **f32)
+        self.flat_target = torch.empty(self.n_params, **f32)
+        self.exp_avg = torch.zeros(self.n_params, **f32)
+        self.exp_avg_sq = torch.zeros(self.n_params, **f32)
+        self.w, self.b, self.wt, self.bt, self.gw, self.gb = [], [], [], [], [], []
+        # everything an update starts from zero sits in ONE allocation (one fill per update): gradients | activations | scalars
+        K0 = self.layers[0].in_features
+        outs = [m.out_features for m in self.layers]
+        act = self.B * sum(outs)
+        self.zeroed = torch.zeros(self.n_params + 2 * act + self.B * sum(outs[:-1]) + self.B * outs[-1] + N.UPD_COUNT, **f32)
+        z = self.zeroed
+        self.grad = z[:self.n_params]
+        off = 0
+        for m, mt in zip(self.layers, self.layers_t):
+            for name in ("weight", "bias"):
+                p, pt = getattr(m, name), getattr(mt, name)
+                n = p.numel()
+                self.flat[off:off + n].copy_(p.detach().reshape(-1))
+                self.flat_target[off:off + n].copy_(pt.detach().reshape(-1))
+                p.data = self.flat[off:off + n].view_as(p)
+                pt.data = self.flat_target[off:off + n].view_as(pt)
+                (self.w if name == "weight" else self.b).append(p.data)
+                (self.wt if name == "weight" else self.bt).append(pt.data)
+                (self.gw if name == "weight" else self.gb).append(self.grad[off:off + n].view_as(p))
+                off += n
+        cur = self.n_params
+        self.z, self.zt, self.da = [], [], []
+        for lst in (self.z, self.zt):                      # pre-activations of the online / the target network
+            for o in outs:
+                lst.append(z[cur:cur + self.B * o].view(self.B, o)); cur += self.B * o
+        for o in outs[:-1]:                                # gradients w.r.t. the hidden activations
+            self.da.append(z[cur:cur + self.B * o].view(self.B, o)); cur += self.B * o
+        self.dq = z[cur:cur + self.B * outs[-1]].view(self.B, outs[-1]); cur += self.B * outs[-1]
+        self.scalars = torch.zeros(N.UPD_COUNT, **f32)     # loss | norm^2 | step | bias corrections | lr   (step persists: not zeroed)
+        self.K0, self.outs = K0, outs
+        self.scalars[N.UPD_LR] = float(lr)
+        # K slices per product: enough wavefronts (16 x 64 tiles x slices) to give every CU work, at least one 16-deep k block each
+        self._tasks_target = 1024
+
+    # ---- helpers -----------------------------------------------------------------------------------------------
+    def _splits(self, M, Nn, K):
+        tiles = ((M + 15) // 16) * ((Nn + 63) // 64)
+        return max(1, min((K + 15) // 16, -(-self._tasks_target // tiles)))
+
+    def _gemm(self, A, Bm, Cm, M, Nn, K, a_sm, a_sk, b_sk, b_sn, flags=0, bias=None, mask=None, row_sum=None, stream=None):
+        rc = self.L.uavenv_gemm_f32(_p(A), _p(Bm), _p(Cm), _p(bias), _p(mask), _p(row_sum), M, Nn, K, a_sm, a_sk, b_sk, b_sn, Cm.stride(0),
+                                    flags, self._splits(M, Nn, K), stream)
+        if rc:
+            raise RuntimeError(f"uavenv_gemm_f32 failed ({rc})")
+
+    def set_lr(self, lr):
+        self.scalars[N.UPD_LR] = float(lr)
+
+    def sync_target(self):
+        """SB3's hard target update (tau = 1)."""
+        self.flat_target.copy_(self.flat)
+
+    @property
+    def loss(self):
+        return self.scalars[N.UPD_LOSS]
+
+    @property
+    def step_count(self):
+        return int(self.scalars[N.UPD_STEP].item())
+
+    def _forward(self, x, ws, bs, zs, stream):
+        B = self.B
+        inp, K, relu_in = x, self.K0, False
+        for W, b, z in zip(ws, bs, zs):
+            n = W.shape[0]
+            # Y[b][n] = bias[n] + sum_k act(X[b][k]) W[n][k]: both operands contiguous along k
+            self._gemm(inp, W, z, B, n, K, inp.stride(0), 1, 1, W.stride(0), flags=N.GEMM_BIAS | (N.GEMM_A_RELU if relu_in else 0), bias=b,
+                       stream=stream)
+            inp, K, relu_in = z, n, True
+
+    # ---- the update ----------------------------------------------------------------------------------------------
+    def backward(self, batch):
+        """sample -> loss -> gradients (in `self.grad`).  batch: dict of the ring's sample_stacked (obs, next_obs, action,
+        reward, valid).  Everything is enqueued on the current stream; nothing synchronises."""
+        B = self.B
+        obs, nxt = batch["obs"], batch["next_obs"]
+        assert obs.shape == (B, self.K0) and obs.is_contiguous() and nxt.is_contiguous() and obs.dtype == torch.float32
+        stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        self.zeroed.zero_()
+        self._forward(obs, self.w, self.b, self.z, stream)
+        self._forward(nxt, self.wt, self.bt, self.zt, stream)
+        valid = batch["valid"]
+        valid_u8 = valid.view(torch.uint8) if valid.dtype == torch.bool else valid
+        rc = self.L.uavenv_td_loss(_p(self.z[-1]), _p(self.zt[-1]), _p(batch["action"]), _p(batch["reward"]), _p(valid_u8), B, self.outs[-1],
+                                   self.gamma, self.reward_scale, self.beta1, self.beta2, _p(self.dq), _p(self.scalars), stream)
+        if rc:
+            raise RuntimeError(f"uavenv_td_loss failed ({rc})")
+        # backward through the layers, last to first; dz_l = da_l masked by (z_l > 0) on the fly (no mask at the output layer)
+        dz, mask = self.dq, None
+        for l in range(len(self.layers) - 1, -1, -1):
+            n = self.outs[l]
+            x_in = obs if l == 0 else self.z[l - 1]
+            K = self.K0 if l == 0 else self.outs[l - 1]
+            mflag = N.GEMM_A_MASK if mask is not None else 0
+            # dW[n][k] = sum_b dz[b][n] act(x[b][k]);  db[n] = sum_b dz[b][n]   (A = dz read transposed, B = x; the sum runs over b)
+            self._gemm(dz, x_in, self.gw[l], n, K, B, 1, dz.stride(0), x_in.stride(0), 1,
+                       flags=mflag | N.GEMM_ROWSUM | (N.GEMM_B_RELU if l > 0 else 0), mask=mask, row_sum=self.gb[l], stream=stream)
+            if l > 0:
+                # da[b][k] = sum_n dz[b][n] W[n][k]
+                self._gemm(dz, self.w[l], self.da[l - 1], B, K, n, dz.stride(0), 1, self.w[l].stride(0), 1, flags=mflag, mask=mask,
+                           stream=stream)
+                dz, mask = self.da[l - 1], self.z[l - 1]
+
+    def apply(self):
+        """clip_grad_norm_ + Adam over the flat buffers, with the gradients as they stand in `self.grad` (several ranks: after
+        their all-reduce)."""
+        stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        rc = self.L.uavenv_grad_sum_squares(_p(self.grad), self.n_params, _p(self.scalars), stream)
+        rc = rc or self.L.uavenv_clip_adam(_p(self.flat), _p(self.grad), _p(self.exp_avg), _p(self.exp_avg_sq), self.n_params, _p(self.scalars),
+                                           self.max_norm, self.beta1, self.beta2, self.eps, stream)
+        if rc:
+            raise RuntimeError(f"uavenv_clip_adam failed ({rc})")
+
+    def update(self, batch):
+        self.backward(batch)
+        self.apply()
+        return self.loss

@@ -323,6 +323,35 @@ int uavenv_attention_weight_floats(int32_t n_stack);
 int uavenv_attention_features(const float* obs_dev, const float* weights_dev, float* out_dev, int32_t batch,
                               int32_t n_stack, void* stream);
 
+/* ---- the learner directly above the path: one DQN gradient step of the MLP policy (dqn.py:1077-1099) ------------------ */
+/* operand transforms / epilogues of uavenv_gemm_f32 */
+#define UAVENV_GEMM_A_RELU   1   /* A is used as max(A, 0): the stored pre-activation of a ReLU layer as the next product's input */
+#define UAVENV_GEMM_A_MASK   2   /* A is used where a_mask (same indexing) > 0, else 0: ReLU's backward                          */
+#define UAVENV_GEMM_B_RELU   4   /* B is used as max(B, 0)                                                                        */
+#define UAVENV_GEMM_BIAS     8   /* bias[n] is added to every row (once)                                                          */
+#define UAVENV_GEMM_ROWSUM  16   /* row_sum[m] += sum_k A(m, k) after the transform: the bias gradient of a weight-gradient product */
+/* scalars block of the update (float [UAVENV_UPD_COUNT]) */
+enum { UAVENV_UPD_LOSS = 0, UAVENV_UPD_NORM2, UAVENV_UPD_STEP, UAVENV_UPD_BC1, UAVENV_UPD_BC2, UAVENV_UPD_LR, UAVENV_UPD_COUNT = 8 };
+/* replaces: torch.nn.Linear's three matrix products (forward, input gradient, weight gradient) at DQN batch sizes, where the
+ * library GEMMs fill 16 of 256 CUs: C[M x N] += A . B on the f32 MFMA, split over K into `splits` slices that are accumulated
+ * with float atomics -- C must hold the addend (zeros) beforehand.  A(m, k) = a_dev[m * a_sm + k * a_sk], B(k, n) =
+ * b_dev[k * b_sk + n * b_sn] (one stride of each pair must be 1), C row-major with ldc.  Needs no UavEnv handle. */
+int uavenv_gemm_f32(const float* a_dev, const float* b_dev, float* c_dev, const float* bias_dev, const float* a_mask_dev,
+                    float* row_sum_dev, int32_t m, int32_t n, int32_t k, int64_t a_sm, int64_t a_sk, int64_t b_sk, int64_t b_sn,
+                    int64_t ldc, int32_t flags, int32_t splits, void* stream);
+/* replaces: the loss of SB3's DQN.train -- smooth-L1 between Q(s, a) and reward_scale * r + gamma * max_a' Q_target(s', a'),
+ * averaged over the valid transitions -- and its gradient dq [batch][n_actions]; also advances scalars[UAVENV_UPD_STEP] and writes
+ * Adam's bias corrections for that step.  batch <= 1024. */
+int uavenv_td_loss(const float* q_dev, const float* q_next_dev, const int64_t* action_dev, const float* reward_dev,
+                   const uint8_t* valid_dev, int32_t batch, int32_t n_actions, float gamma, float reward_scale, float beta1, float beta2,
+                   float* dq_dev, float* scalars_dev, void* stream);
+/* replaces: torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step (SB3 DQN: max_grad_norm 10, Adam) over ONE flat buffer of
+ * n parameters: uavenv_grad_sum_squares adds sum g^2 to scalars[UAVENV_UPD_NORM2] (uavenv_td_loss zeroes it), uavenv_clip_adam scales the
+ * gradient by min(1, max_norm / (norm + 1e-6)) and applies Adam with the learning rate in scalars[UAVENV_UPD_LR]. */
+int uavenv_grad_sum_squares(const float* grad_dev, int64_t n, float* scalars_dev, void* stream);
+int uavenv_clip_adam(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n,
+                     const float* scalars_dev, float max_norm, float beta1, float beta2, float eps, void* stream);
+
 /* ---- state access (checkpoint / parity / the attribute reads of SURVEY 1) -------------------- */
 /* Copies one whole field.  `bytes` must equal the field size; dst/src may be host or device.
  * A state handed to uavenv_set_state must be one the library could have produced: 0 <= data_buffer <= max_buffer_size in every

@@ -95,6 +95,7 @@ def test_config3_learner_4096x50_graph_path_equals_eager_and_oracle(extractor, n
         L.learn(total_timesteps=E * steps)
     torch.cuda.synchronize()
     assert Lg._act_graphs is not None and Lg._train_graph is not None and Le._act_graphs is None
+    assert (Lg._mlp is not None) == (extractor == "mlp")          # the MLP policy's update runs in the library's own kernels
     # (a rollout is followed by an update once the ring holds n_stack + 2 slots: 9 of the 10 rollouts with 4 frames, 8 with 10)
     assert Lg.n_updates == Le.n_updates == (9 if n_stack == 4 else 8) and Lg.n_calls == Le.n_calls == steps
     rg, re_ = Lg.ring, Le.ring
@@ -109,8 +110,8 @@ def test_config3_learner_4096x50_graph_path_equals_eager_and_oracle(extractor, n
     #  the transitions the replay drew)
     import copy
     q0, t0 = copy.deepcopy(Lg.q), copy.deepcopy(Lg.q_target)
-    opt0 = torch.optim.Adam(q0.parameters(), lr=torch.tensor(0.0, device=Lg.dev), capturable=True)
-    opt0.load_state_dict(copy.deepcopy(Lg.opt.state_dict()))
+    from test_gpu_learner import _torch_adam_twin
+    opt0 = _torch_adam_twin(torch, Lg, q0)
     Lg.train(1)
     torch.cuda.synchronize()
     j, slot, r, e = [Lg._g_index[i] for i in range(4)]

@@ -21,6 +21,23 @@ def _mods():
     return torch, U, LR
 
 
+def _torch_adam_twin(torch, L, q0):
+    """A torch.optim.Adam over the copy `q0` of the learner's online network, in the learner's optimiser state -- whichever form
+    the learner keeps it in (torch's own, or the fused update's flat moment buffers and step count)."""
+    import copy
+    opt0 = torch.optim.Adam(q0.parameters(), lr=torch.tensor(0.0, device=L.dev), capturable=True)
+    if L._mlp is None:
+        opt0.load_state_dict(copy.deepcopy(L.opt.state_dict()))
+        return opt0
+    off, step = 0, float(L._mlp.step_count)
+    for p in q0.parameters():
+        n = p.numel()
+        opt0.state[p] = {"step": torch.tensor(step, device=L.dev), "exp_avg": L._mlp.exp_avg[off:off + n].view_as(p).clone(),
+                         "exp_avg_sq": L._mlp.exp_avg_sq[off:off + n].view_as(p).clone()}
+        off += n
+    return opt0
+
+
 def test_reference_hyperparameters_and_schedules():
     torch, U, LR = _mods()
     hp = LR.REFERENCE_HYPERPARAMS
@@ -44,14 +61,17 @@ def test_reference_hyperparameters_and_schedules():
     env.close()
 
 
-def test_one_update_matches_hand_written_arithmetic():
-    """TD target / smooth-L1 / valid mask / clipping / Adam on a fixed batch drawn with `sample_stacked`."""
+@pytest.mark.parametrize("fused", [True, False], ids=["hip_update", "torch_update"])
+def test_one_update_matches_hand_written_arithmetic(fused):
+    """TD target / smooth-L1 / valid mask / clipping / Adam on a fixed batch drawn with `sample_stacked` -- through the library's
+    own update kernels (the default for the MLP policy) and through torch autograd + torch.optim.Adam."""
     torch, U, LR = _mods()
     E, k, gamma = 96, 3, 0.9
     env = U.BatchedUAVEnv(E, num_sensors=10, max_steps=9, grid_size=(60, 60), seed=5)
     L = LR.DQNLearner(env, learning_rate=1e-2, buffer_size=96 * 40, batch_size=64, gamma=gamma, learning_starts=0,
                       target_update_interval=96 * 1000, train_freq=1, gradient_steps=1, net_arch=(32,), n_stack=k,
-                      total_timesteps=10**6, max_grad_norm=0.5, seed=3, reward_scale=1e-3)
+                      total_timesteps=10**6, max_grad_norm=0.5, seed=3, reward_scale=1e-3, fused_update=fused)
+    assert (L._mlp is not None) == fused
     L.collect(30)
     with torch.no_grad():                     # make the target network differ from the online one
         for p in L.q_target.parameters():
@@ -199,7 +219,8 @@ def test_graph_replay_of_the_acting_loop_writes_what_the_eager_loop_writes():
         e.close()
 
 
-def test_graph_replay_of_the_update_is_the_eager_update_on_the_same_draw():
+@pytest.mark.parametrize("fused", [True, False], ids=["hip_update", "torch_update"])
+def test_graph_replay_of_the_update_is_the_eager_update_on_the_same_draw(fused):
     """The captured gradient step (sample -> TD loss -> backward -> clip -> Adam) against the same step done by hand in
     eager mode on the transitions the replay drew (`_g_index`), from the same weights and optimiser state."""
     import copy
@@ -207,12 +228,11 @@ def test_graph_replay_of_the_update_is_the_eager_update_on_the_same_draw():
     env = U.BatchedUAVEnv(96, num_sensors=10, max_steps=9, grid_size=(60, 60), seed=5)
     L = LR.DQNLearner(env, learning_rate=1e-2, buffer_size=96 * 40, batch_size=64, gamma=0.9, learning_starts=0,
                       target_update_interval=96 * 7, train_freq=2, gradient_steps=1, net_arch=(32, 16), n_stack=3,
-                      total_timesteps=10**6, max_grad_norm=0.5, seed=3, reward_scale=1e-3, use_graphs=True)
+                      total_timesteps=10**6, max_grad_norm=0.5, seed=3, reward_scale=1e-3, use_graphs=True, fused_update=fused)
     L.learn(total_timesteps=96 * 2 * 8)            # 8 rollouts: the first 3 updates are eager, then the graph is captured
     assert L._train_graph is not None and L.n_updates >= 5
     q0, t0 = copy.deepcopy(L.q), copy.deepcopy(L.q_target)
-    opt0 = torch.optim.Adam(q0.parameters(), lr=torch.tensor(0.0, device=env.device), capturable=True)
-    opt0.load_state_dict(copy.deepcopy(L.opt.state_dict()))
+    opt0 = _torch_adam_twin(torch, L, q0)
     before = [p.detach().clone() for p in L.q.parameters()]
     L.train(1)                                     # one replay
     torch.cuda.synchronize()
@@ -230,8 +250,9 @@ def test_graph_replay_of_the_update_is_the_eager_update_on_the_same_draw():
     torch.nn.utils.clip_grad_norm_(q0.parameters(), 0.5)
     opt0.step()
     assert float(loss.detach()) == pytest.approx(float(L.last_loss), rel=1e-5)
+    tol = dict(rtol=1e-4, atol=1e-6) if fused else dict(rtol=1e-5, atol=1e-7)      # (split-K partial sums in another order)
     for p, w in zip(L.q.parameters(), q0.parameters()):
-        assert torch.allclose(p.detach(), w.detach(), rtol=1e-5, atol=1e-7)
+        assert torch.allclose(p.detach(), w.detach(), **tol), float((p.detach() - w.detach()).abs().max())
     env.close()
 
 

@@ -14,7 +14,7 @@ for v in "$@"; do
   n="${v%%=*}"; f="${v#*=}"
   names="$names $n"
   if [ "${f#@}" != "$f" ]; then cp "${f#@}" tools/_exp/lib_$n.so; continue; fi     # name=@/path/lib.so: a library built earlier
-  ( /opt/rocm/bin/hipcc $FLAGS $f -o tools/_exp/lib_$n.so "$PKG/csrc/uavenv_kernels.hip" "$PKG/csrc/uavenv_capi.hip" "$PKG/csrc/uavenv_attention.hip" "$PKG/csrc/uavenv_replay.hip" 2> tools/_exp/build_$n.log || echo "BUILD FAILED $n" ) &
+  ( /opt/rocm/bin/hipcc $FLAGS $f -o tools/_exp/lib_$n.so "$PKG/csrc/uavenv_kernels.hip" "$PKG/csrc/uavenv_capi.hip" "$PKG/csrc/uavenv_attention.hip" "$PKG/csrc/uavenv_replay.hip" "$PKG/csrc/uavenv_learner.hip" 2> tools/_exp/build_$n.log || echo "BUILD FAILED $n" ) &
 done
 wait
 grep -l "error" tools/_exp/build_*.log 2>/dev/null && { grep -h "error" tools/_exp/build_*.log | head; exit 1; }
