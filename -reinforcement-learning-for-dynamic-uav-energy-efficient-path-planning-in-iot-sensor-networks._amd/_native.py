@@ -18,7 +18,7 @@ FLAG_RANDOM_LAYOUT, FLAG_FAR_START, FLAG_PROX_SHAPING, FLAG_JAIN_BONUS, FLAG_AUT
 E_INVALID, E_HIP, E_ACTION, E_ALLOC = -1, -2, -3, -4
 POLICY_ACTIONS, POLICY_RANDOM, POLICY_NEAREST, POLICY_MAX_THROUGHPUT_V2 = 0, 1, 2, 3
 GEMM_A_RELU, GEMM_A_MASK, GEMM_B_RELU, GEMM_BIAS, GEMM_ROWSUM = 1, 2, 4, 8, 16
-UPD_LOSS, UPD_NORM2, UPD_STEP, UPD_BC1, UPD_BC2, UPD_LR, UPD_COUNT = 0, 1, 2, 3, 4, 5, 8
+UPD_LOSS, UPD_NORM2, UPD_STEP, UPD_BC1, UPD_BC2, UPD_LR, UPD_COUNT, UPD_WORKSPACE = 0, 1, 2, 3, 4, 5, 8, 256
 ABI_VERSION = 2
 
 
@@ -79,11 +79,18 @@ class UavRingLayout(C.Structure):
                 ("obs_floats", C.c_int32), ("term_off", C.c_int32), ("count_off", C.c_int32)]
 
 
+class UavGemm(C.Structure):
+    """include/uavenv.h:UavGemm (one product of uavenv_gemm_f32)."""
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p), ("a_mask", C.c_void_p), ("row_sum", C.c_void_p),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("flags", C.c_int32),
+                ("a_sm", C.c_int64), ("a_sk", C.c_int64), ("b_sk", C.c_int64), ("b_sn", C.c_int64), ("ldc", C.c_int64)]
+
+
 EXPORTS = [
     "uavenv_abi_version", "uavenv_default_config", "uavenv_obs_dim", "uavenv_create", "uavenv_destroy",
     "uavenv_last_error", "uavenv_num_envs", "uavenv_lane_stride", "uavenv_env_obs_dim", "uavenv_set_env_params",
     "uavenv_set_positions", "uavenv_set_seed", "uavenv_get_config", "uavenv_set_config", "uavenv_set_grid_choices", "uavenv_set_noise_tape",
-    "uavenv_dump_noise", "uavenv_reset", "uavenv_step", "uavenv_step_random", "uavenv_step_random_n", "uavenv_step_policy", "uavenv_rollout", "uavenv_frame_stack", "uavenv_ring_gather_stacked", "uavenv_set_terminal_pool", "uavenv_set_aux_output", "uavenv_enable_terminal_snapshot", "uavenv_attention_weight_floats", "uavenv_attention_features", "uavenv_gemm_f32", "uavenv_td_loss", "uavenv_grad_sum_squares", "uavenv_clip_adam", "uavenv_get_state",
+    "uavenv_dump_noise", "uavenv_reset", "uavenv_step", "uavenv_step_random", "uavenv_step_random_n", "uavenv_step_policy", "uavenv_rollout", "uavenv_frame_stack", "uavenv_ring_gather_stacked", "uavenv_ring_sample_stacked", "uavenv_set_terminal_pool", "uavenv_set_aux_output", "uavenv_enable_terminal_snapshot", "uavenv_attention_weight_floats", "uavenv_attention_features", "uavenv_gemm_f32", "uavenv_td_loss", "uavenv_clip_adam", "uavenv_get_state",
     "uavenv_set_state", "uavenv_state_bytes", "uavenv_reset_host", "uavenv_step_host", "uavenv_time_steps",
 ]
 
@@ -149,12 +156,12 @@ def _load(path):
         "uavenv_enable_terminal_snapshot": (C.c_int, [vp, i32]),
         "uavenv_attention_weight_floats": (C.c_int, [i32]),
         "uavenv_attention_features": (C.c_int, [vp, vp, vp, i32, i32, vp]),
-        "uavenv_gemm_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, i32, i32, vp]),
+        "uavenv_gemm_f32": (C.c_int, [C.POINTER(UavGemm), C.POINTER(UavGemm), vp]),
         "uavenv_td_loss": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp, vp]),
-        "uavenv_grad_sum_squares": (C.c_int, [vp, C.c_int64, vp, vp]),
-        "uavenv_clip_adam": (C.c_int, [vp, vp, vp, vp, C.c_int64, vp, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
+        "uavenv_clip_adam": (C.c_int, [vp, vp, vp, vp, C.c_int64, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
         "uavenv_frame_stack": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
         "uavenv_ring_gather_stacked": (C.c_int, [vp, C.POINTER(UavRingLayout), vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+        "uavenv_ring_sample_stacked": (C.c_int, [vp, C.POINTER(UavRingLayout), vp, vp, u64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
         "uavenv_get_state": (C.c_int, [vp, i32, vp, C.c_size_t, i32, vp]),
         "uavenv_set_state": (C.c_int, [vp, i32, vp, C.c_size_t, i32, vp]),
         "uavenv_state_bytes": (C.c_size_t, [vp, i32]),

@@ -11,9 +11,10 @@
 //     forward   Y[b][n]  += sum_k X[b][k] W[n][k]      (both operands contiguous along k)
 //     input     dX[b][k] += sum_n dZ[b][n] W[n][k]
 //     weight    dW[n][k] += sum_b dZ[b][n] X[b][k]     (+ bias gradient = row sums of the transposed operand)
-// a wavefront owns a 16 x 64 output tile of a K-SLICE (split-K: 1000-2000 wavefronts per product, every CU busy), fragments come
-// straight from global memory (everything is L2 resident: 2.8 MB of weights, < 1 MB of activations), partial tiles are added
-// with hardware float atomics into zeroed outputs.  ReLU is never a pass of its own: a layer stores its PRE-activation and the
+// a workgroup of 16 wavefronts owns a 16 x 64 (or 16 x 32) output tile and splits K among its wavefronts (128-640 workgroups per
+// product: every CU busy, four wavefronts per SIMD hiding each other's loads), fragments come straight from global memory
+// (everything is L2 resident: 2.8 MB of weights, < 1 MB of activations), the partial tiles meet in LDS and are stored once.
+// ReLU is never a pass of its own: a layer stores its PRE-activation and the
 // consumer applies max(., 0) -- or, backward, the (z > 0) mask -- while loading the operand.  Around it: the TD loss with its
 // gradient in one workgroup, the global gradient norm, and clip + Adam over ONE flat parameter buffer.
 // fp32 throughout; parity is against torch autograd + torch.optim.Adam on the same batch (tests/test_gpu_mlp_update.py).
@@ -26,21 +27,12 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct GemmArgs {
-    const float* A; const float* B; float* C;
-    const float* bias;        // UAVENV_GEMM_BIAS: added once (by the first K slice) to every row
-    const float* a_mask;      // UAVENV_GEMM_A_MASK: same indexing as A; A is used where a_mask > 0, else 0 (ReLU backward)
-    float* row_sum;           // UAVENV_GEMM_ROWSUM: row_sum[m] += sum_k A(m, k) after the transform (bias gradient)
-    int32_t M, N, K;
-    int64_t a_sm, a_sk, b_sk, b_sn, ldc;      // element (m, k) of A at A[m * a_sm + k * a_sk]; (k, n) of B at B[k * b_sk + n * b_sn]
-    int32_t flags, splits;
-};
+typedef UavGemm GemmArgs;     // include/uavenv.h: operands, strides, flags of one product
 
 __device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // four consecutive-k elements of an operand: `p` points at element (row, k); contiguous along k (KC) or strided by `sk`
-template <bool KC>
-__device__ __forceinline__ f32x4 load_k4(const float* p, int64_t sk, int k, int K, bool row_ok) {
+__device__ __forceinline__ f32x4 load_k4(bool KC, const float* p, int64_t sk, int k, int K, bool row_ok) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (!row_ok) return v;
     if (KC) {
@@ -59,42 +51,49 @@ __device__ __forceinline__ f32x4 load_k4(const float* p, int64_t sk, int k, int 
 }
 __device__ __forceinline__ f32x4 relu4(f32x4 v) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); return v; }
 
-// C[M x N] += A[M x K] . B[K x N]; M, N and K are arbitrary (guards on the tails).  One wavefront: rows
-// 16 * im .., columns 64 * in .., k blocks [kb0, kb1) of 16.  MFMA operand map: lane l = (row / column r = l & 15, k group g = l >> 4)
-// holds k = 16 * kb + 4 * g + t in step t -- any assignment works as long as A and B use the same one.
-template <bool AK, bool BK>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
-    const int lane = threadIdx.x & 63;
-    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int mt = (g.M + 15) >> 4, nt = (g.N + 63) >> 6;
-    if (task >= mt * nt * g.splits) return;
-    const int split = task / (mt * nt), rem = task - split * (mt * nt);
-    const int im = rem % mt, in = rem / mt;
-    const int kblocks = (g.K + 15) >> 4, per = (kblocks + g.splits - 1) / g.splits;
-    const int kb0 = split * per, kb1 = min(kblocks, kb0 + per);
+// C[M x N] = A[M x K] . B[K x N] (+ bias); M, N and K are arbitrary (guards on the tails).  One WORKGROUP of 16 wavefronts owns
+// one 16 x (16 * NSUB) output tile; wavefront w takes the k blocks w, w + 16, ... (split-K inside the workgroup), the 16 partial
+// tiles meet in LDS and every thread adds up one element and stores it: no atomics (device-scope float atomics on 8 XCDs were
+// what the first form of this kernel spent its 13 us on), no zeroed outputs.  MFMA operand map: lane l = (row / column
+// r = l & 15, k group g = l >> 4) holds k = 16 * kb + 4 * g + t in step t -- any assignment works as long as A and B share it.
+// Two independent products may share a launch (the online and the target network's forward of a layer; a layer's weight gradient and
+// the gradient w.r.t. its input): workgroups [0, tiles0) belong to g0, the rest to g1 -- every launch saved is ~5 us of dispatch and
+// cold-cache latency that a 2 us product cannot hide.
+template <int NSUB>
+__global__ __launch_bounds__(1024) void gemm_f32_kernel(GemmArgs g0, GemmArgs g1, int tiles0) {
+    constexpr int kCols = 16 * NSUB, kTile = 16 * kCols;
+    __shared__ float red[16][kTile + 16];
+    const bool second = (int)blockIdx.x >= tiles0;
+    const GemmArgs& g = second ? g1 : g0;
+    const int tile = second ? (int)blockIdx.x - tiles0 : (int)blockIdx.x;
+    const bool AK = g.a_sk == 1, BK = g.b_sk == 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mt = (g.M + 15) >> 4;
+    const int im = tile % mt, in = tile / mt;
+    const int kblocks = (g.K + 15) >> 4;
     const int r = lane & 15, gq = lane >> 4;
     const int m = im * 16 + r;
     const bool a_relu = (g.flags & UAVENV_GEMM_A_RELU) != 0, a_mask = (g.flags & UAVENV_GEMM_A_MASK) != 0;
     const bool b_relu = (g.flags & UAVENV_GEMM_B_RELU) != 0;
     const bool want_rowsum = (g.flags & UAVENV_GEMM_ROWSUM) != 0 && in == 0;
-    f32x4 acc[4];
+    f32x4 acc[NSUB];
 #pragma unroll
-    for (int j = 0; j < 4; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NSUB; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float rowsum = 0.f;
-    for (int kb = kb0; kb < kb1; kb++) {
+    for (int kb = wave; kb < kblocks; kb += 16) {
         const int k = kb * 16 + 4 * gq;
         const int64_t a_off = (int64_t)m * g.a_sm + (int64_t)k * g.a_sk;
-        f32x4 a = load_k4<AK>(g.A + a_off, g.a_sk, k, g.K, m < g.M);
+        f32x4 a = load_k4(AK, g.A + a_off, g.a_sk, k, g.K, m < g.M);
         if (a_relu) a = relu4(a);
         if (a_mask) {
-            const f32x4 z = load_k4<AK>(g.a_mask + a_off, g.a_sk, k, g.K, m < g.M);
+            const f32x4 z = load_k4(AK, g.a_mask + a_off, g.a_sk, k, g.K, m < g.M);
             a.x = z.x > 0.f ? a.x : 0.f; a.y = z.y > 0.f ? a.y : 0.f; a.z = z.z > 0.f ? a.z : 0.f; a.w = z.w > 0.f ? a.w : 0.f;
         }
         if (want_rowsum) rowsum += (a.x + a.y) + (a.z + a.w);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int n = in * 64 + 16 * j + r;
-            f32x4 b = load_k4<BK>(g.B + (int64_t)k * g.b_sk + (int64_t)n * g.b_sn, g.b_sk, k, g.K, n < g.N);
+        for (int j = 0; j < NSUB; j++) {
+            const int n = in * kCols + 16 * j + r;
+            f32x4 b = load_k4(BK, g.B + (int64_t)k * g.b_sk + (int64_t)n * g.b_sn, g.b_sk, k, g.K, n < g.N);
             if (b_relu) b = relu4(b);
             acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[j], 0, 0, 0);
             acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[j], 0, 0, 0);
@@ -102,25 +101,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[j], 0, 0, 0);
         }
     }
-    if (kb1 <= kb0) return;
-    // result tile: lane holds column r, rows 4 * gq + i
-    const bool add_bias = (g.flags & UAVENV_GEMM_BIAS) != 0 && split == 0;
+    // partial tile -> LDS (lane: column 16 j + r, rows 4 gq + i)
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int n = in * 64 + 16 * j + r;
-        if (n >= g.N) continue;
-        const float bv = add_bias ? g.bias[n] : 0.f;
-        const float v[4] = {acc[j].x, acc[j].y, acc[j].z, acc[j].w};
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int mm = im * 16 + 4 * gq + i;
-            if (mm < g.M) unsafeAtomicAdd(g.C + (int64_t)mm * g.ldc + n, v[i] + bv);
-        }
+    for (int j = 0; j < NSUB; j++) {
+        float* p = &red[wave][(4 * gq) * kCols + 16 * j + r];
+        p[0] = acc[j].x; p[kCols] = acc[j].y; p[2 * kCols] = acc[j].z; p[3 * kCols] = acc[j].w;
     }
     if (want_rowsum) {                                        // the four k groups of a row sit 16 lanes apart
         rowsum += __shfl_xor(rowsum, 16);
         rowsum += __shfl_xor(rowsum, 32);
-        if (gq == 0 && m < g.M) unsafeAtomicAdd(g.row_sum + m, rowsum);
+        if (gq == 0) red[wave][kTile + r] = rowsum;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < kTile; e += 1024) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; w++) v += red[w][e];
+        const int mm = im * 16 + e / kCols, n = in * kCols + e % kCols;
+        if (mm < g.M && n < g.N) g.C[(int64_t)mm * g.ldc + n] = v + ((g.flags & UAVENV_GEMM_BIAS) ? g.bias[n] : 0.f);
+    }
+    if (want_rowsum && threadIdx.x < 16) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; w++) v += red[w][kTile + threadIdx.x];
+        if (im * 16 + (int)threadIdx.x < g.M) g.row_sum[im * 16 + threadIdx.x] = v;
     }
 }
 
@@ -159,7 +163,6 @@ __global__ __launch_bounds__(1024) void td_loss_kernel(const float* __restrict__
     }
     if (threadIdx.x == 0) {
         scalars[UAVENV_UPD_LOSS] = lt * inv;
-        scalars[UAVENV_UPD_NORM2] = 0.f;                       // uavenv_grad_sum_squares adds into it
         const float t = scalars[UAVENV_UPD_STEP] + 1.f;
         scalars[UAVENV_UPD_STEP] = t;
         scalars[UAVENV_UPD_BC1] = 1.f - powf(beta1, t);
@@ -167,18 +170,31 @@ __global__ __launch_bounds__(1024) void td_loss_kernel(const float* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void sum_squares_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+// gradient norm in two steps without atomics: every workgroup leaves the sum of squares of its share in partial[blockIdx.x] ...
+constexpr int kNormBlocks = 256;
+__global__ __launch_bounds__(256) void sum_squares_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ partial) {
+    __shared__ float sw[4];
     float s = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += g[i] * g[i];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(out, s);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
 }
 
+// ... and every workgroup of the optimiser kernel adds the kNormBlocks partials up again (1 KB from L2).
 // torch.nn.utils.clip_grad_norm_(max_norm) followed by torch.optim.Adam.step() (no weight decay, no amsgrad) over flat buffers
 __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2,
-                                                      int64_t n, const float* __restrict__ scalars, float max_norm, float beta1, float beta2, float eps) {
-    const float norm = sqrtf(scalars[UAVENV_UPD_NORM2]);
-    const float coef = fminf(max_norm / (norm + 1e-6f), 1.0f);
+                                                      int64_t n, float* __restrict__ scalars, const float* __restrict__ partial, float max_norm,
+                                                      float beta1, float beta2, float eps) {
+    __shared__ float sw[4];
+    float s = partial[threadIdx.x];                            // blockDim.x == kNormBlocks
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float norm2 = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) scalars[UAVENV_UPD_NORM2] = norm2;
+    const float coef = fminf(max_norm / (sqrtf(norm2) + 1e-6f), 1.0f);
     const float lr = scalars[UAVENV_UPD_LR], bc1 = scalars[UAVENV_UPD_BC1], bc2s = sqrtf(scalars[UAVENV_UPD_BC2]);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float gi = g[i] * coef;
@@ -192,27 +208,27 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
 }  // namespace
 
 // replaces: the three matrix products of torch.nn.Linear's forward / backward at DQN batch sizes (dqn.py:1086 batch_size 256).
-// C[M x N] += A . B with A(m, k) = A_dev[m * a_sm + k * a_sk], B(k, n) = B_dev[k * b_sk + n * b_sn]; C row-major with ldc, and it
-// must hold the addend already (zeros for a plain product: the K slices are accumulated with float atomics).
-// One of a_sm / a_sk (b_sk / b_sn) must be 1; flags UAVENV_GEMM_*; splits >= 1 = number of K slices.
-extern "C" int uavenv_gemm_f32(const float* a_dev, const float* b_dev, float* c_dev, const float* bias_dev, const float* a_mask_dev,
-                               float* row_sum_dev, int32_t m, int32_t n, int32_t k, int64_t a_sm, int64_t a_sk, int64_t b_sk, int64_t b_sn,
-                               int64_t ldc, int32_t flags, int32_t splits, void* stream) {
-    if (!a_dev || !b_dev || !c_dev || m < 1 || n < 1 || k < 1 || splits < 1 || ldc < n) return UAVENV_E_INVALID;
-    if ((a_sm != 1 && a_sk != 1) || (b_sk != 1 && b_sn != 1)) return UAVENV_E_INVALID;
-    if (((flags & UAVENV_GEMM_BIAS) && !bias_dev) || ((flags & UAVENV_GEMM_A_MASK) && !a_mask_dev) || ((flags & UAVENV_GEMM_ROWSUM) && !row_sum_dev))
-        return UAVENV_E_INVALID;
-    GemmArgs g{a_dev, b_dev, c_dev, bias_dev, a_mask_dev, row_sum_dev, m, n, k, a_sm, a_sk, b_sk, b_sn, ldc, flags, splits};
-    const int kblocks = (k + 15) / 16;
-    if (g.splits > kblocks) g.splits = kblocks;
-    const long tasks = (long)((m + 15) / 16) * ((n + 63) / 64) * g.splits;
-    const dim3 grid((unsigned)((tasks + 3) / 4)), block(256);
-    const bool ak = a_sk == 1, bk = b_sk == 1;
+// C[M x N] = A . B (+ bias) with A(m, k) = A[m * a_sm + k * a_sk], B(k, n) = B[k * b_sk + n * b_sn]; C row-major with ldc.
+// One of a_sm / a_sk (b_sk / b_sn) must be 1; flags UAVENV_GEMM_*.  `second` (nullable): an independent product in the same launch.
+static bool gemm_ok(const UavGemm* g) {
+    if (!g->A || !g->B || !g->C || g->M < 1 || g->N < 1 || g->K < 1 || g->ldc < g->N) return false;
+    if ((g->a_sm != 1 && g->a_sk != 1) || (g->b_sk != 1 && g->b_sn != 1)) return false;
+    return !(((g->flags & UAVENV_GEMM_BIAS) && !g->bias) || ((g->flags & UAVENV_GEMM_A_MASK) && !g->a_mask) ||
+             ((g->flags & UAVENV_GEMM_ROWSUM) && !g->row_sum));
+}
+extern "C" int uavenv_gemm_f32(const UavGemm* first, const UavGemm* second, void* stream) {
+    if (!first || !gemm_ok(first) || (second && !gemm_ok(second))) return UAVENV_E_INVALID;
+    auto tiles = [](const UavGemm* g, int cols) { return (long)((g->M + 15) / 16) * ((g->N + cols - 1) / cols); };
+    // 16 x 64 tiles, or 16 x 32 when that is what it takes to give every CU a workgroup
+    const long wide = tiles(first, 64) + (second ? tiles(second, 64) : 0);
+    const bool narrow = wide < 256;
+    const int cols = narrow ? 32 : 64;
+    const long t0 = tiles(first, cols), t1 = second ? tiles(second, cols) : 0;
+    const dim3 grid((unsigned)(t0 + t1)), block(1024);
     hipStream_t s = (hipStream_t)stream;
-    if (ak && bk) gemm_f32_kernel<true, true><<<grid, block, 0, s>>>(g);
-    else if (ak) gemm_f32_kernel<true, false><<<grid, block, 0, s>>>(g);
-    else if (bk) gemm_f32_kernel<false, true><<<grid, block, 0, s>>>(g);
-    else gemm_f32_kernel<false, false><<<grid, block, 0, s>>>(g);
+    const UavGemm& g1 = second ? *second : *first;
+    if (narrow) gemm_f32_kernel<2><<<grid, block, 0, s>>>(*first, g1, (int)t0);
+    else gemm_f32_kernel<4><<<grid, block, 0, s>>>(*first, g1, (int)t0);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_E_HIP;
 }
 
@@ -230,19 +246,15 @@ extern "C" int uavenv_td_loss(const float* q_dev, const float* q_next_dev, const
 }
 
 // replaces: clip_grad_norm_(parameters, max_norm) + Adam.step() of SB3's DQN.train over ONE flat buffer of n parameters
-// (the caller keeps the module's parameters as views of it).  uavenv_grad_sum_squares adds sum g^2 to scalars[UAVENV_UPD_NORM2]
-// (uavenv_td_loss zeroes it); uavenv_clip_adam reads it, the learning rate scalars[UAVENV_UPD_LR] and the bias corrections uavenv_td_loss wrote.
-extern "C" int uavenv_grad_sum_squares(const float* grad_dev, int64_t n, float* scalars_dev, void* stream) {
-    if (!grad_dev || !scalars_dev || n < 1) return UAVENV_E_INVALID;
-    const unsigned blocks = (unsigned)((n + 256 * 8 - 1) / (256 * 8) < 1024 ? (n + 256 * 8 - 1) / (256 * 8) : 1024);
-    sum_squares_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(grad_dev, n, scalars_dev + UAVENV_UPD_NORM2);
-    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_E_HIP;
-}
+// (the caller keeps the module's parameters as views of it): two launches -- sums of squares per workgroup into workspace_dev
+// (float [UAVENV_UPD_WORKSPACE]), then clip + Adam with the learning rate scalars[UAVENV_UPD_LR] and the bias corrections
+// uavenv_td_loss wrote; scalars[UAVENV_UPD_NORM2] receives the squared gradient norm.
 extern "C" int uavenv_clip_adam(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n,
-                                const float* scalars_dev, float max_norm, float beta1, float beta2, float eps, void* stream) {
-    if (!param_dev || !grad_dev || !exp_avg_dev || !exp_avg_sq_dev || !scalars_dev || n < 1) return UAVENV_E_INVALID;
+                                float* scalars_dev, float* workspace_dev, float max_norm, float beta1, float beta2, float eps, void* stream) {
+    if (!param_dev || !grad_dev || !exp_avg_dev || !exp_avg_sq_dev || !scalars_dev || !workspace_dev || n < 1) return UAVENV_E_INVALID;
+    sum_squares_kernel<<<dim3(kNormBlocks), dim3(256), 0, (hipStream_t)stream>>>(grad_dev, n, workspace_dev);
     const unsigned blocks = (unsigned)((n + 256 * 4 - 1) / (256 * 4) < 2048 ? (n + 256 * 4 - 1) / (256 * 4) : 2048);
-    clip_adam_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(param_dev, grad_dev, exp_avg_dev, exp_avg_sq_dev, n, scalars_dev,
-                                                                        max_norm, beta1, beta2, eps);
+    clip_adam_kernel<<<dim3(blocks), dim3(kNormBlocks), 0, (hipStream_t)stream>>>(param_dev, grad_dev, exp_avg_dev, exp_avg_sq_dev, n, scalars_dev,
+                                                                               workspace_dev, max_norm, beta1, beta2, eps);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_E_HIP;
 }

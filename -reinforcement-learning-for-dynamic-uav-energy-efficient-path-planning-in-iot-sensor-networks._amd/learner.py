@@ -224,7 +224,8 @@ class DQNLearner:
                 tunable.write_file_on_exit(False)               # library versions it was made with); written by _finish_tuning
             except Exception:
                 pass
-        self.gen = torch.Generator(device=self.dev).manual_seed(seed * 7919 + 13 + self.rank)
+        self._sample_seed = seed * 7919 + 13 + self.rank          # every rank draws its own share of a batch
+        self.gen = torch.Generator(device=self.dev).manual_seed(self._sample_seed)
         # replay: buffer_size transitions = buffer_size // n_envs vector slots (SB3 ReplayBuffer), in chunks (one terminal
         # section and, across ranks, one collective per chunk); one chunk is always being recycled, hence the extra one
         slots = max(int(buffer_size) // self.n_envs_total, self.k + 2)
@@ -350,6 +351,23 @@ class DQNLearner:
         dist.all_reduce(self._flat_grad)
         self._flat_grad.div_(self.world)
 
+    def _sample(self, window=None):
+        """A batch of this rank's share of the update.  With the library's own update the draw happens inside the gather kernel,
+        keyed by (seed, optimiser step): one launch, the same draw whether the step runs eagerly or as a graph replay; otherwise
+        the ring draws with the learner's torch generator."""
+        if self._mlp is not None:
+            if window is None:
+                self.ring.drain()
+                n, oldest = self.ring.window_state()
+                if self.__dict__.get("_win2") is None:
+                    self._win2 = torch.zeros(2, dtype=torch.int64, device=self.dev)
+                self._win2[0] = n; self._win2[1] = oldest
+                window = self._win2
+            self._keyed_out = self.ring.sample_stacked_keyed(self.local_batch, self.k, window, self._mlp.scalars[N.UPD_STEP:N.UPD_STEP + 1],
+                                                             self._sample_seed, out=self.__dict__.get("_keyed_out"))
+            return self._keyed_out
+        return self.ring.sample_stacked(self.local_batch, self.k, generator=self.gen, window=window)
+
     def _backward(self, batch):
         """Loss and gradients of one batch (several ranks: the gradients end up in the flat buffer the all-reduce works on).
         Returns the detached loss."""
@@ -384,7 +402,8 @@ class DQNLearner:
         (optimizer state and library workspaces exist); the ring's sampling window and the learning rate are device scalars
         refreshed before each replay.  With several ranks the step is TWO graphs around the host-issued gradient all-reduce:
         [sample -> loss -> backward (-> flatten)] and [(unflatten ->) clip -> Adam]."""
-        self._g_win = (torch.zeros((), dtype=torch.int64, device=self.dev), torch.zeros((), dtype=torch.int64, device=self.dev))
+        self._g_win2 = torch.zeros(2, dtype=torch.int64, device=self.dev)
+        self._g_win = (self._g_win2[0], self._g_win2[1])
         self._g_loss = torch.zeros((), device=self.dev)
         self._g_index = torch.zeros(4, self.local_batch, dtype=torch.int64, device=self.dev)    # the last replay's draw (tests)
         n, oldest = self.ring.window_state()
@@ -395,9 +414,13 @@ class DQNLearner:
         g.register_generator_state(self.gen)
         pool = torch.cuda.graph_pool_handle()
         with torch.cuda.graph(g, pool=pool):
-            batch = self.ring.sample_stacked(self.local_batch, self.k, generator=self.gen, window=self._g_win)
-            self._g_loss.copy_(self._backward(batch))
-            self._g_index.copy_(torch.stack(batch["index"]))
+            batch = self._sample(window=self._g_win2 if self._mlp is not None else self._g_win)
+            loss = self._backward(batch)
+            if self._mlp is not None:                     # (the library's update leaves both in buffers of its own: no copies)
+                self._g_loss, self._g_index = loss, batch["index_block"]
+            else:
+                self._g_loss.copy_(loss)
+                self._g_index.copy_(torch.stack(batch["index"]))
             if self.world == 1:
                 self._apply()
         self._train_graph = g
@@ -470,7 +493,7 @@ class DQNLearner:
             return self._g_loss
         loss = None
         for _ in range(steps):
-            batch = self.ring.sample_stacked(self.local_batch, self.k, generator=self.gen)
+            batch = self._sample()
             loss = self._backward(batch)
             if self.world > 1:                                     # replicas stay identical: one all-reduce of the flat gradient
                 self._allreduce_grads()

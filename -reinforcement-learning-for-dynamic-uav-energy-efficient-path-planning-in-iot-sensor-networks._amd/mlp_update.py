@@ -1,4 +1,4 @@
-"""One DQN gradient step of the reference's MLP policy as ~20 HIP launches (csrc/uavenv_learner.hip) instead of ~60 PyTorch
+"""One DQN gradient step of the reference's MLP policy as 12 HIP launches (csrc/uavenv_learner.hip) instead of ~60 PyTorch
 ones: what stable-baselines3's `DQN.train()` does per gradient step for `MlpPolicy` with `net_arch=[512, 512, 256]`
 (agents/dqn/dqn.py:1077-1099) -- forward of the online and the target network, smooth-L1 TD loss, backward, clip_grad_norm_,
 Adam -- on one sampled batch.  torch is plumbing here (device buffers, the modules whose parameters become views of one flat
@@ -50,12 +50,13 @@ class FusedMLPUpdate:
         self.exp_avg = torch.zeros(self.n_params, **f32)
         self.exp_avg_sq = torch.zeros(self.n_params, **f32)
         self.w, self.b, self.wt, self.bt, self.gw, self.gb = [], [], [], [], [], []
-        # everything an update starts from zero sits in ONE allocation (one fill per update): gradients | activations | scalars
+        # gradients | activations in ONE allocation (every product overwrites its whole output: nothing has to be zeroed)
         K0 = self.layers[0].in_features
         outs = [m.out_features for m in self.layers]
         act = self.B * sum(outs)
-        self.zeroed = torch.zeros(self.n_params + 2 * act + self.B * sum(outs[:-1]) + self.B * outs[-1] + N.UPD_COUNT, **f32)
-        z = self.zeroed
+        self.work = torch.zeros(self.n_params + 2 * act + self.B * sum(outs[:-1]) + self.B * outs[-1], **f32)
+        self.norm_workspace = torch.zeros(N.UPD_WORKSPACE, **f32)
+        z = self.work
         self.grad = z[:self.n_params]
         off = 0
         for m, mt in zip(self.layers, self.layers_t):
@@ -81,17 +82,16 @@ class FusedMLPUpdate:
         self.scalars = torch.zeros(N.UPD_COUNT, **f32)     # loss | norm^2 | step | bias corrections | lr   (step persists: not zeroed)
         self.K0, self.outs = K0, outs
         self.scalars[N.UPD_LR] = float(lr)
-        # K slices per product: enough wavefronts (16 x 64 tiles x slices) to give every CU work, at least one 16-deep k block each
-        self._tasks_target = 1024
 
     # ---- helpers -----------------------------------------------------------------------------------------------
-    def _splits(self, M, Nn, K):
-        tiles = ((M + 15) // 16) * ((Nn + 63) // 64)
-        return max(1, min((K + 15) // 16, -(-self._tasks_target // tiles)))
+    @staticmethod
+    def _product(A, Bm, Cm, M, Nn, K, a_sm, a_sk, b_sk, b_sn, flags=0, bias=None, mask=None, row_sum=None):
+        dp = lambda t: None if t is None else t.data_ptr()
+        return N.UavGemm(A=dp(A), B=dp(Bm), C=dp(Cm), bias=dp(bias), a_mask=dp(mask), row_sum=dp(row_sum), M=M, N=Nn, K=K, flags=flags,
+                         a_sm=a_sm, a_sk=a_sk, b_sk=b_sk, b_sn=b_sn, ldc=Cm.stride(0))
 
-    def _gemm(self, A, Bm, Cm, M, Nn, K, a_sm, a_sk, b_sk, b_sn, flags=0, bias=None, mask=None, row_sum=None, stream=None):
-        rc = self.L.uavenv_gemm_f32(_p(A), _p(Bm), _p(Cm), _p(bias), _p(mask), _p(row_sum), M, Nn, K, a_sm, a_sk, b_sk, b_sn, Cm.stride(0),
-                                    flags, self._splits(M, Nn, K), stream)
+    def _launch(self, first, second, stream):
+        rc = self.L.uavenv_gemm_f32(C.byref(first), None if second is None else C.byref(second), stream)
         if rc:
             raise RuntimeError(f"uavenv_gemm_f32 failed ({rc})")
 
@@ -110,27 +110,26 @@ class FusedMLPUpdate:
     def step_count(self):
         return int(self.scalars[N.UPD_STEP].item())
 
-    def _forward(self, x, ws, bs, zs, stream):
-        B = self.B
-        inp, K, relu_in = x, self.K0, False
-        for W, b, z in zip(ws, bs, zs):
-            n = W.shape[0]
-            # Y[b][n] = bias[n] + sum_k act(X[b][k]) W[n][k]: both operands contiguous along k
-            self._gemm(inp, W, z, B, n, K, inp.stride(0), 1, 1, W.stride(0), flags=N.GEMM_BIAS | (N.GEMM_A_RELU if relu_in else 0), bias=b,
-                       stream=stream)
-            inp, K, relu_in = z, n, True
+    def _forward_layer(self, l, x, ws, bs, zs):
+        """Y[b][n] = bias[n] + sum_k act(X[b][k]) W[n][k] of layer l: both operands contiguous along k"""
+        inp = x if l == 0 else zs[l - 1]
+        K = self.K0 if l == 0 else self.outs[l - 1]
+        W = ws[l]
+        return self._product(inp, W, zs[l], self.B, W.shape[0], K, inp.stride(0), 1, 1, W.stride(0),
+                             flags=N.GEMM_BIAS | (N.GEMM_A_RELU if l > 0 else 0), bias=bs[l])
 
     # ---- the update ----------------------------------------------------------------------------------------------
     def backward(self, batch):
         """sample -> loss -> gradients (in `self.grad`).  batch: dict of the ring's sample_stacked (obs, next_obs, action,
-        reward, valid).  Everything is enqueued on the current stream; nothing synchronises."""
+        reward, valid).  Everything is enqueued on the current stream; nothing synchronises.  9 launches: a layer of the online
+        and of the target network share one, so do a layer's weight gradient and the gradient w.r.t. its input."""
         B = self.B
         obs, nxt = batch["obs"], batch["next_obs"]
         assert obs.shape == (B, self.K0) and obs.is_contiguous() and nxt.is_contiguous() and obs.dtype == torch.float32
         stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
-        self.zeroed.zero_()
-        self._forward(obs, self.w, self.b, self.z, stream)
-        self._forward(nxt, self.wt, self.bt, self.zt, stream)
+        nl = len(self.layers)
+        for l in range(nl):
+            self._launch(self._forward_layer(l, obs, self.w, self.b, self.z), self._forward_layer(l, nxt, self.wt, self.bt, self.zt), stream)
         valid = batch["valid"]
         valid_u8 = valid.view(torch.uint8) if valid.dtype == torch.bool else valid
         rc = self.L.uavenv_td_loss(_p(self.z[-1]), _p(self.zt[-1]), _p(batch["action"]), _p(batch["reward"]), _p(valid_u8), B, self.outs[-1],
@@ -139,27 +138,28 @@ class FusedMLPUpdate:
             raise RuntimeError(f"uavenv_td_loss failed ({rc})")
         # backward through the layers, last to first; dz_l = da_l masked by (z_l > 0) on the fly (no mask at the output layer)
         dz, mask = self.dq, None
-        for l in range(len(self.layers) - 1, -1, -1):
+        for l in range(nl - 1, -1, -1):
             n = self.outs[l]
             x_in = obs if l == 0 else self.z[l - 1]
             K = self.K0 if l == 0 else self.outs[l - 1]
             mflag = N.GEMM_A_MASK if mask is not None else 0
             # dW[n][k] = sum_b dz[b][n] act(x[b][k]);  db[n] = sum_b dz[b][n]   (A = dz read transposed, B = x; the sum runs over b)
-            self._gemm(dz, x_in, self.gw[l], n, K, B, 1, dz.stride(0), x_in.stride(0), 1,
-                       flags=mflag | N.GEMM_ROWSUM | (N.GEMM_B_RELU if l > 0 else 0), mask=mask, row_sum=self.gb[l], stream=stream)
+            dw = self._product(dz, x_in, self.gw[l], n, K, B, 1, dz.stride(0), x_in.stride(0), 1,
+                               flags=mflag | N.GEMM_ROWSUM | (N.GEMM_B_RELU if l > 0 else 0), mask=mask, row_sum=self.gb[l])
+            dx = None
             if l > 0:
                 # da[b][k] = sum_n dz[b][n] W[n][k]
-                self._gemm(dz, self.w[l], self.da[l - 1], B, K, n, dz.stride(0), 1, self.w[l].stride(0), 1, flags=mflag, mask=mask,
-                           stream=stream)
+                dx = self._product(dz, self.w[l], self.da[l - 1], B, K, n, dz.stride(0), 1, self.w[l].stride(0), 1, flags=mflag, mask=mask)
+            self._launch(dw, dx, stream)
+            if l > 0:
                 dz, mask = self.da[l - 1], self.z[l - 1]
 
     def apply(self):
         """clip_grad_norm_ + Adam over the flat buffers, with the gradients as they stand in `self.grad` (several ranks: after
         their all-reduce)."""
         stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
-        rc = self.L.uavenv_grad_sum_squares(_p(self.grad), self.n_params, _p(self.scalars), stream)
-        rc = rc or self.L.uavenv_clip_adam(_p(self.flat), _p(self.grad), _p(self.exp_avg), _p(self.exp_avg_sq), self.n_params, _p(self.scalars),
-                                           self.max_norm, self.beta1, self.beta2, self.eps, stream)
+        rc = self.L.uavenv_clip_adam(_p(self.flat), _p(self.grad), _p(self.exp_avg), _p(self.exp_avg_sq), self.n_params, _p(self.scalars),
+                                     _p(self.norm_workspace), self.max_norm, self.beta1, self.beta2, self.eps, stream)
         if rc:
             raise RuntimeError(f"uavenv_clip_adam failed ({rc})")
 

@@ -323,6 +323,35 @@ class TransitionRing:
             raise RuntimeError(f"uavenv_ring_gather_stacked failed ({rc})")
         return dict(obs=obs, action=action, reward=reward, done=done, next_obs=nxt, valid=valid, index=(j, slot, r, e))
 
+    def sample_stacked_keyed(self, batch_size, n_stack, window, counter, seed, out=None):
+        """sample_stacked with the draw made inside the gather kernel (uavenv_ring_sample_stacked): `window` = int64 cuda tensor [2]
+        (sampleable slots, position of the oldest), `counter` = float32 cuda scalar that differs from draw to draw, `seed` = the
+        Philox key.  One launch in all; replayable as part of a captured graph (the caller drains pending gathers and refreshes
+        `window` before each replay).  `out`: a dict of preallocated output tensors from an earlier call (reused in place)."""
+        import ctypes as C
+        from . import _native as N
+        if self.__dict__.get("_layout") is None:
+            self._layout = N.UavRingLayout(section=self.section, num_chunks=self.n_chunks, world=self.world, slots_per_chunk=self.L,
+                                           envs=self.E, obs_dim=self.D, terminal_rows=self.T, block=self.block,
+                                           obs_floats=self.obs_floats, term_off=self.term_off, count_off=self.count_off)
+            self._glib = N.lib()
+        dev, k, B = self.device, int(n_stack), int(batch_size)
+        assert window.is_cuda and window.dtype == torch.int64 and window.numel() == 2 and counter.is_cuda and counter.dtype == torch.float32
+        if out is None:
+            out = dict(obs=torch.empty(B, k * self.D, dtype=torch.float32, device=dev), next_obs=torch.empty(B, k * self.D, dtype=torch.float32, device=dev),
+                       action=torch.empty(B, dtype=torch.int64, device=dev), reward=torch.empty(B, dtype=torch.float32, device=dev),
+                       done=torch.empty(B, dtype=torch.bool, device=dev), valid=torch.empty(B, dtype=torch.bool, device=dev),
+                       index_block=torch.empty(4, B, dtype=torch.int64, device=dev))
+            out["index"] = tuple(out["index_block"][i] for i in range(4))
+        p = lambda t: C.c_void_p(t.data_ptr())
+        rc = self._glib.uavenv_ring_sample_stacked(p(self.store), C.byref(self._layout), p(window), p(counter), int(seed) & 0xFFFFFFFFFFFFFFFF, B, k,
+                                                   p(out["obs"]), p(out["next_obs"]), p(out["action"]), p(out["reward"]), p(out["done"]),
+                                                   p(out["valid"]), p(out["index_block"]),
+                                                   C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc:
+            raise RuntimeError(f"uavenv_ring_sample_stacked failed ({rc})")
+        return out
+
     def sample(self, batch_size, generator=None):
         """Uniform sample of transitions (obs, action, reward, done, next_obs, valid) over all ranks' envs.
         Slot s holds the observation s_t together with (a, r, done) of the step that PRODUCED it, so the

@@ -314,6 +314,16 @@ int uavenv_ring_gather_stacked(const float* store_dev, const UavRingLayout* layo
                                float* obs_out_dev, float* next_obs_out_dev, int64_t* action_out_dev, float* reward_out_dev,
                                uint8_t* done_out_dev, uint8_t* valid_out_dev, void* stream);
 
+/* same with the draw made IN the kernel (replaces the ~10 PyTorch launches that draw slot / rank / environment of a batch): sample b of
+ * draw number *counter_dev gets Philox4x32 words keyed by (seed; b, counter): age uniform on 0 .. n-2, rank uniform on the ranks,
+ * environment uniform on a rank's environments.  window_dev int64 [2] = (n = number of sampleable slots, ring position of the oldest);
+ * counter_dev float [1] must differ from draw to draw (e.g. the optimiser's step count) -- both in device memory, so that a captured
+ * launch draws a fresh batch at every replay.  index_out_dev int64 [4][batch] (nullable): the draw (age, slot, rank, environment). */
+int uavenv_ring_sample_stacked(const float* store_dev, const UavRingLayout* layout, const int64_t* window_dev, const float* counter_dev,
+                               uint64_t seed, int32_t batch, int32_t num_frames, float* obs_out_dev, float* next_obs_out_dev,
+                               int64_t* action_out_dev, float* reward_out_dev, uint8_t* done_out_dev, uint8_t* valid_out_dev,
+                               int64_t* index_out_dev, void* stream);
+
 /* ---- the consumer of the observation layout: UAVAttentionExtractor forward (dqn.py:548-650) ------------- */
 /* replaces: UAVAttentionExtractor.forward for inference, fused into one launch.  obs_dev float
  * [batch][n_stack*153] (the frame-stacked, 50-slot padded observation), weights_dev = the extractor's parameters
@@ -332,13 +342,20 @@ int uavenv_attention_features(const float* obs_dev, const float* weights_dev, fl
 #define UAVENV_GEMM_ROWSUM  16   /* row_sum[m] += sum_k A(m, k) after the transform: the bias gradient of a weight-gradient product */
 /* scalars block of the update (float [UAVENV_UPD_COUNT]) */
 enum { UAVENV_UPD_LOSS = 0, UAVENV_UPD_NORM2, UAVENV_UPD_STEP, UAVENV_UPD_BC1, UAVENV_UPD_BC2, UAVENV_UPD_LR, UAVENV_UPD_COUNT = 8 };
+/* one product C[M x N] = A . B (+ bias): A(m, k) = A[m * a_sm + k * a_sk], B(k, n) = B[k * b_sk + n * b_sn] (one stride of each
+ * pair must be 1), C row-major with ldc; all device pointers */
+typedef struct UavGemm {
+    const float* A; const float* B; float* C;
+    const float* bias;        /* UAVENV_GEMM_BIAS   */
+    const float* a_mask;      /* UAVENV_GEMM_A_MASK: indexed like A */
+    float* row_sum;           /* UAVENV_GEMM_ROWSUM: float [M]      */
+    int32_t M, N, K, flags;
+    int64_t a_sm, a_sk, b_sk, b_sn, ldc;
+} UavGemm;
 /* replaces: torch.nn.Linear's three matrix products (forward, input gradient, weight gradient) at DQN batch sizes, where the
- * library GEMMs fill 16 of 256 CUs: C[M x N] += A . B on the f32 MFMA, split over K into `splits` slices that are accumulated
- * with float atomics -- C must hold the addend (zeros) beforehand.  A(m, k) = a_dev[m * a_sm + k * a_sk], B(k, n) =
- * b_dev[k * b_sk + n * b_sn] (one stride of each pair must be 1), C row-major with ldc.  Needs no UavEnv handle. */
-int uavenv_gemm_f32(const float* a_dev, const float* b_dev, float* c_dev, const float* bias_dev, const float* a_mask_dev,
-                    float* row_sum_dev, int32_t m, int32_t n, int32_t k, int64_t a_sm, int64_t a_sk, int64_t b_sk, int64_t b_sn,
-                    int64_t ldc, int32_t flags, int32_t splits, void* stream);
+ * library GEMMs fill 16 of 256 CUs: on the f32 MFMA, one workgroup per 16 x 64 (or 16 x 32) output tile with K split over its 16
+ * wavefronts.  `second` (nullable) is an independent product that shares the launch.  Needs no UavEnv handle. */
+int uavenv_gemm_f32(const UavGemm* first, const UavGemm* second, void* stream);
 /* replaces: the loss of SB3's DQN.train -- smooth-L1 between Q(s, a) and reward_scale * r + gamma * max_a' Q_target(s', a'),
  * averaged over the valid transitions -- and its gradient dq [batch][n_actions]; also advances scalars[UAVENV_UPD_STEP] and writes
  * Adam's bias corrections for that step.  batch <= 1024. */
@@ -346,11 +363,12 @@ int uavenv_td_loss(const float* q_dev, const float* q_next_dev, const int64_t* a
                    const uint8_t* valid_dev, int32_t batch, int32_t n_actions, float gamma, float reward_scale, float beta1, float beta2,
                    float* dq_dev, float* scalars_dev, void* stream);
 /* replaces: torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step (SB3 DQN: max_grad_norm 10, Adam) over ONE flat buffer of
- * n parameters: uavenv_grad_sum_squares adds sum g^2 to scalars[UAVENV_UPD_NORM2] (uavenv_td_loss zeroes it), uavenv_clip_adam scales the
- * gradient by min(1, max_norm / (norm + 1e-6)) and applies Adam with the learning rate in scalars[UAVENV_UPD_LR]. */
-int uavenv_grad_sum_squares(const float* grad_dev, int64_t n, float* scalars_dev, void* stream);
+ * n parameters: the gradient is scaled by min(1, max_norm / (norm + 1e-6)) and Adam applied with the learning rate in
+ * scalars[UAVENV_UPD_LR] and the bias corrections uavenv_td_loss left; scalars[UAVENV_UPD_NORM2] receives the squared norm.
+ * workspace_dev: float [UAVENV_UPD_WORKSPACE]. */
+#define UAVENV_UPD_WORKSPACE 256
 int uavenv_clip_adam(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n,
-                     const float* scalars_dev, float max_norm, float beta1, float beta2, float eps, void* stream);
+                     float* scalars_dev, float* workspace_dev, float max_norm, float beta1, float beta2, float eps, void* stream);
 
 /* ---- state access (checkpoint / parity / the attribute reads of SURVEY 1) -------------------- */
 /* Copies one whole field.  `bytes` must equal the field size; dst/src may be host or device.

@@ -432,3 +432,40 @@ def test_hip_ring_gather_equals_the_pytorch_statement():
     assert bool(got["done"].any()) and not bool(got["valid"].all()) and bool(got["valid"].any())
     assert bool((got["obs"][:40, :D] == 0).all())                          # the frames from before the ring start are zero
     env.close()
+
+
+def test_keyed_in_kernel_draw_is_uniform_and_equals_the_gather_at_its_indices():
+    """uavenv_ring_sample_stacked: the draw made inside the gather kernel.  Same counter -> same batch; another counter -> another
+    batch; the batch equals stacked_batch_at() at the indices it reports; ages / ranks / environments cover their ranges evenly."""
+    torch, U, O = _mods()
+    E, k = 48, 3
+    env = U.BatchedUAVEnv(E, num_sensors=10, grid_size=(50, 50), max_steps=11, seed=8)
+    ring = U.TransitionRing(40, E, env.obs_dim, env.device, chunk_len=8)
+    ring.attach(env)
+    ring.local_obs_slot().copy_(env.reset())
+    z = torch.zeros(E, device=env.device)
+    ring.commit(z, z, z)
+    for _ in range(60):
+        env.step_random(obs_out=ring.local_obs_slot())
+        ring.commit()
+    n, oldest = ring.window_state()
+    window = torch.tensor([n, oldest], dtype=torch.int64, device=env.device)
+    counter = torch.zeros(1, device=env.device)
+    a = ring.sample_stacked_keyed(4096, k, window, counter, seed=123)
+    a = {key: (v.clone() if torch.is_tensor(v) else tuple(t.clone() for t in v)) for key, v in a.items()}
+    b = ring.sample_stacked_keyed(4096, k, window, counter, seed=123)
+    assert all(torch.equal(a[key], b[key]) for key in ("obs", "next_obs", "action", "reward", "done", "valid", "index_block"))
+    counter.fill_(1.0)
+    c = ring.sample_stacked_keyed(4096, k, window, counter, seed=123)
+    assert not torch.equal(a["index_block"], c["index_block"])
+    j, slot, r, e = a["index"]
+    assert int(j.min()) == 0 and int(j.max()) == n - 2 and torch.equal(slot, (oldest + j) % ring.capacity) and int(r.max()) == 0
+    assert int(e.min()) == 0 and int(e.max()) == E - 1
+    cnt_e = torch.bincount(e, minlength=E).float()
+    cnt_j = torch.bincount(j, minlength=n - 1).float()
+    assert float(cnt_e.min()) > 0.5 * 4096 / E and float(cnt_j.min()) > 0.4 * 4096 / (n - 1)
+    want = ring.stacked_batch_at(j, slot, r, e, k)
+    for key in ("obs", "next_obs", "action", "reward", "done", "valid"):
+        assert torch.equal(a[key], want[key]), key
+    assert bool(a["done"].any())
+    env.close()

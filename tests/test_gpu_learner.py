@@ -77,7 +77,10 @@ def test_one_update_matches_hand_written_arithmetic(fused):
         for p in L.q_target.parameters():
             p.mul_(0.5)
     gen_state = L.gen.get_state()
-    batch = L.ring.sample_stacked(64, k, generator=L.gen)
+    if fused:          # the library's update draws inside the gather kernel, keyed by (seed, optimiser step): train(1) below repeats it
+        batch = {k_: (v.clone() if torch.is_tensor(v) else tuple(t.clone() for t in v)) for k_, v in L._sample().items()}
+    else:
+        batch = L.ring.sample_stacked(64, k, generator=L.gen)
     assert batch["done"].any() and batch["valid"].all() and batch["obs"].shape == (64, k * env.obs_dim)
     # ---- by hand -------------------------------------------------------------------------------------------
     W1, b1, W2, b2 = [p.detach().double().clone() for p in L.q.parameters()]

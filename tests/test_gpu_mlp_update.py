@@ -1,7 +1,7 @@
 """GPU: the hand-written DQN update of the MLP policy (csrc/uavenv_learner.hip, uavenv_amd/mlp_update.py) against PyTorch --
 the small-batch MFMA GEMM with its operand transforms against torch.matmul, and whole updates (forward of both networks,
 smooth-L1 TD loss, backward, clip_grad_norm_, Adam) against torch autograd + torch.optim.Adam on the same batches.
-Floating-point kernels: fp32 sums in another order than the library's (split-K partial tiles added with float atomics) ->
+Floating-point kernels: fp32 sums in another order than the library's (K split over the wavefronts of a workgroup) ->
 tolerances 1e-4 relative / 1e-5 absolute on O(1) values."""
 import ctypes as C
 
@@ -20,53 +20,65 @@ def _mods():
     return torch, U, N, LR, FusedMLPUpdate
 
 
-def _gemm(torch, N, A, B, Cm, M, Nn, K, a_sm, a_sk, b_sk, b_sn, flags=0, bias=None, mask=None, row_sum=None, splits=4):
-    p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
-    rc = N.lib().uavenv_gemm_f32(p(A), p(B), p(Cm), p(bias), p(mask), p(row_sum), M, Nn, K, a_sm, a_sk, b_sk, b_sn, Cm.stride(0), flags, splits,
-                                 C.c_void_p(torch.cuda.current_stream().cuda_stream))
+def _product(N, A, B, Cm, M, Nn, K, a_sm, a_sk, b_sk, b_sn, flags=0, bias=None, mask=None, row_sum=None):
+    dp = lambda t: None if t is None else t.data_ptr()
+    return N.UavGemm(A=dp(A), B=dp(B), C=dp(Cm), bias=dp(bias), a_mask=dp(mask), row_sum=dp(row_sum), M=M, N=Nn, K=K, flags=flags,
+                     a_sm=a_sm, a_sk=a_sk, b_sk=b_sk, b_sn=b_sn, ldc=Cm.stride(0))
+
+
+def _gemm(torch, N, A, B, Cm, M, Nn, K, a_sm, a_sk, b_sk, b_sn, flags=0, bias=None, mask=None, row_sum=None, second=None):
+    g = _product(N, A, B, Cm, M, Nn, K, a_sm, a_sk, b_sk, b_sn, flags, bias, mask, row_sum)
+    rc = N.lib().uavenv_gemm_f32(C.byref(g), None if second is None else C.byref(second), C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0, rc
 
 
-@pytest.mark.parametrize("M,Nn,K,splits", [(256, 512, 612, 8), (256, 5, 256, 16), (64, 70, 33, 3), (16, 64, 16, 1), (5, 256, 256, 4), (512, 612, 256, 4)])
-def test_small_batch_gemm_all_three_layouts_match_torch(M, Nn, K, splits):
+@pytest.mark.parametrize("M,Nn,K", [(256, 512, 612), (256, 5, 256), (64, 70, 33), (16, 64, 16), (5, 256, 256), (512, 612, 256), (256, 256, 5)])
+def test_small_batch_gemm_all_three_layouts_match_torch(M, Nn, K):
     torch, U, N, LR, F = _mods()
     g = torch.Generator(device="cuda").manual_seed(M * 1000 + Nn)
     r = lambda *s: torch.randn(*s, device="cuda", generator=g)
     # forward layout: A [M x K] and W [N x K] contiguous along k, bias, relu on A
     A, W, bias = r(M, K), r(Nn, K), r(Nn)
-    Cm = torch.zeros(M, Nn, device="cuda")
-    _gemm(torch, N, A, W, Cm, M, Nn, K, K, 1, 1, K, flags=N.GEMM_BIAS | N.GEMM_A_RELU, bias=bias, splits=splits)
+    Cm = torch.full((M, Nn), 7.0, device="cuda")             # (every product overwrites its whole output)
+    _gemm(torch, N, A, W, Cm, M, Nn, K, K, 1, 1, K, flags=N.GEMM_BIAS | N.GEMM_A_RELU, bias=bias)
     want = torch.relu(A).double() @ W.double().t() + bias.double()
     assert torch.allclose(Cm.double(), want, rtol=1e-4, atol=1e-4 * K ** 0.5), float((Cm.double() - want).abs().max())
     # input-gradient layout: A [M x K] contiguous along k, B [K x N] contiguous along n, mask on A
     Bm, Z = r(K, Nn), r(M, K)
-    Cm.zero_()
-    _gemm(torch, N, A, Bm, Cm, M, Nn, K, K, 1, Nn, 1, flags=N.GEMM_A_MASK, mask=Z, splits=splits)
+    _gemm(torch, N, A, Bm, Cm, M, Nn, K, K, 1, Nn, 1, flags=N.GEMM_A_MASK, mask=Z)
     want = (A * (Z > 0)).double() @ Bm.double()
     assert torch.allclose(Cm.double(), want, rtol=1e-4, atol=1e-4 * K ** 0.5)
     # weight-gradient layout: A(m, k) = S[k][m] (transposed read), B [K x N] contiguous along n with relu, row sums of A
-    S, rs = r(K, M), torch.zeros(M, device="cuda")
-    Cm.zero_()
-    _gemm(torch, N, S, Bm, Cm, M, Nn, K, 1, M, Nn, 1, flags=N.GEMM_B_RELU | N.GEMM_ROWSUM, row_sum=rs, splits=splits)
+    S, rs = r(K, M), torch.full((M,), 3.0, device="cuda")
+    _gemm(torch, N, S, Bm, Cm, M, Nn, K, 1, M, Nn, 1, flags=N.GEMM_B_RELU | N.GEMM_ROWSUM, row_sum=rs)
     want = S.double().t() @ torch.relu(Bm).double()
     assert torch.allclose(Cm.double(), want, rtol=1e-4, atol=1e-4 * K ** 0.5)
     assert torch.allclose(rs.double(), S.double().sum(0), rtol=1e-4, atol=1e-4 * K ** 0.5)
-    # a strided output (a sub-block of a wider matrix) and an accumulating call
+    # a strided output (a sub-block of a wider matrix): nothing outside it is touched
     wide = torch.ones(M, Nn + 7, device="cuda")
     sub = wide[:, 3:3 + Nn]
-    _gemm(torch, N, A, W, sub, M, Nn, K, K, 1, 1, K, splits=splits)
-    assert torch.allclose(sub.double(), 1.0 + A.double() @ W.double().t(), rtol=1e-4, atol=1e-4 * K ** 0.5)
+    _gemm(torch, N, A, W, sub, M, Nn, K, K, 1, 1, K)
+    assert torch.allclose(sub.double(), A.double() @ W.double().t(), rtol=1e-4, atol=1e-4 * K ** 0.5)
     assert bool((wide[:, :3] == 1).all()) and bool((wide[:, 3 + Nn:] == 1).all())
+    # two independent products of different layouts in ONE launch (a weight gradient and an input gradient, as the update pairs them)
+    C1, C2 = torch.zeros(M, Nn, device="cuda"), torch.zeros(M, K, device="cuda")
+    W2 = r(Nn, K)
+    second = _product(N, Cm, W2, C2, M, K, Nn, Nn, 1, K, 1)                  # C2[m][k] = sum_n Cm[m][n] W2[n][k]
+    _gemm(torch, N, S, Bm, C1, M, Nn, K, 1, M, Nn, 1, second=second)
+    assert torch.allclose(C1.double(), S.double().t() @ Bm.double(), rtol=1e-4, atol=1e-4 * K ** 0.5)
+    assert torch.allclose(C2.double(), Cm.double() @ W2.double(), rtol=1e-4, atol=2e-4 * (Nn * K) ** 0.5)
 
 
 def test_gemm_rejects_bad_arguments():
     torch, U, N, LR, F = _mods()
     a = torch.zeros(16, 16, device="cuda")
     L = N.lib()
-    p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
-    assert L.uavenv_gemm_f32(p(a), p(a), p(a), None, None, None, 16, 16, 16, 16, 2, 1, 16, 16, 0, 1, None) == N.E_INVALID      # no unit stride in A
-    assert L.uavenv_gemm_f32(p(a), p(a), p(a), None, None, None, 16, 16, 16, 16, 1, 1, 16, 16, N.GEMM_BIAS, 1, None) == N.E_INVALID  # bias flag, no bias
-    assert L.uavenv_gemm_f32(None, p(a), p(a), None, None, None, 16, 16, 16, 16, 1, 1, 16, 16, 0, 1, None) == N.E_INVALID
+    ok = _product(N, a, a, a, 16, 16, 16, 16, 1, 1, 16)
+    assert L.uavenv_gemm_f32(C.byref(_product(N, a, a, a, 16, 16, 16, 16, 2, 1, 16)), None, None) == N.E_INVALID      # no unit stride in A
+    assert L.uavenv_gemm_f32(C.byref(_product(N, a, a, a, 16, 16, 16, 16, 1, 1, 16, flags=N.GEMM_BIAS)), None, None) == N.E_INVALID   # bias flag, no bias
+    assert L.uavenv_gemm_f32(C.byref(_product(N, None, a, a, 16, 16, 16, 16, 1, 1, 16)), None, None) == N.E_INVALID
+    assert L.uavenv_gemm_f32(C.byref(ok), C.byref(_product(N, a, None, a, 16, 16, 16, 16, 1, 1, 16)), None) == N.E_INVALID    # a bad second product
+    assert L.uavenv_gemm_f32(None, None, None) == N.E_INVALID
 
 
 def _batch(torch, B, K0, seed, n_invalid=9):
