@@ -31,3 +31,24 @@ def test_bench_line_has_the_contract_fields():
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     assert r["algorithmic_bytes_per_env_step"] == 68 * 50 + 104
     assert "cpu_baseline" in d and d["fused_rollout"]["steps_per_launch"] == 4
+
+
+def test_bench_two_rank_path_rehearsed_on_one_gpu():
+    """The N > 1 path of bench.py exactly as the driver launches it (`python -m torch.distributed.run --nproc-per-node N ... bench.py
+    --gpus N`), rehearsed with two ranks on this one GPU over gloo (UAVENV_BENCH_REHEARSE=gloo: RCCL needs a GPU per rank): sharded
+    environments, the chunk all-gather into the shared ring, barrier + max-over-ranks timing, ONE JSON line from rank 0 whose value
+    counts the environment steps of BOTH ranks.  No scaling number is claimed from it (both ranks share the GPU)."""
+    env = dict(os.environ, UAVENV_BENCH_REHEARSE="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29600 + (os.getpid() % 300)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "64", "--warmup", "16", "--fused", "0"]
+    r = subprocess.run(cmd, text=True, capture_output=True, cwd=ROOT, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 64 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert abs(d["ms_per_step"] * 1e-3 * d["value"] - 2 * 4096) < 1e-3 * 2 * 4096     # whole-job aggregate: both shards' environments
+    assert "all_gather" in d["config"]["exchange"] and "exchange_error" not in d["config"]
+    assert "REHEARSAL" in d["config"]["parallelism"]
+    assert d["shard_only"]["env_steps_per_s"] > 0
