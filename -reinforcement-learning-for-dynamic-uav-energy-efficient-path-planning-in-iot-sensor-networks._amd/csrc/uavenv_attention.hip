@@ -320,8 +320,14 @@ __global__ __launch_bounds__(kThreads) void uav_attention_kernel(const float* __
             const f32x4* a4 = reinterpret_cast<const f32x4*>(As);
             const f32x4* t4 = reinterpret_cast<const f32x4*>(Ts);
             f32x2 m0 = z2, m1 = z2, m2 = z2, m3 = z2;
+            // (a pair of masked tokens has zero attention weight in every head: ghost slots and out-of-range sensors are most of a
+            //  typical observation, and the pair mask is wave-uniform)
+            const unsigned long long live = __ballot(!masked);
 #pragma unroll 5
             for (int sp = 0; sp < 25; sp++) {
+#ifndef ATTN_NO_SKIP
+                if (((live >> (2 * sp)) & 3ull) == 0ull) continue;
+#endif
                 const f32x4 ta = t4[2 * sp], a01 = a4[2 * sp], a23 = a4[2 * sp + 1];
                 const f32x2 tb = *reinterpret_cast<const f32x2*>(Ts + sp * kPairRow + 4);
                 f32x2 e = c_sw0 * lo(ta);
