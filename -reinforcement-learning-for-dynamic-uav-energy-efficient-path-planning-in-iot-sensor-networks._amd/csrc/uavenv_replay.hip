@@ -63,14 +63,18 @@ __global__ __launch_bounds__(256) void uav_ring_gather_kernel(RingView rv, const
     const int D = g.obs_dim;
     // frame f (0 = oldest) sits k-1-f slots behind `slot`; it belongs to the transition's episode iff no LATER frame of the
     // stack is the first observation of an episode (aux.done of a slot: the step INTO it ended one) and the ring reaches back
-    // that far (age j counts slots from the oldest sampleable one)
-    // (newest frame first, so that "an episode started after this frame" is known when the frame is copied)
-    bool later_start = false;
+    // that far (age j counts slots from the oldest sampleable one).  All k episode-start flags are fetched first (lane f reads
+    // frame f's), so that the row copies below are independent loads instead of a chain of k dependent ones.
     float* orow = obs_out + (size_t)b * k * D;
     float* nrow = next_out + (size_t)b * k * D;
-    for (int f = k - 1; f >= 0; f--) {
+    float start_flag = 0.0f;
+    if (lane < k) start_flag = rv.aux(((((slot - (k - 1 - lane)) % cap) + cap) % cap), r, e)[2];
+    const unsigned long long starts = __ballot(start_flag > 0.5f);            // bit f: frame f is the first of an episode
+#pragma unroll 4
+    for (int f = 0; f < k; f++) {
         const long back = k - 1 - f;
         const long fs = (((slot - back) % cap) + cap) % cap;
+        const bool later_start = (starts >> (f + 1)) != 0ull;                 // (frame f's own flag only matters to the frames older than f)
         const float keep = (!later_start && (j - back) >= 0) ? 1.0f : 0.0f;
         const float* src = rv.obs(fs, r, e);
         for (int c = lane; c < D; c += 64) {
@@ -78,7 +82,6 @@ __global__ __launch_bounds__(256) void uav_ring_gather_kernel(RingView rv, const
             orow[f * D + c] = v;
             if (f >= 1) nrow[(f - 1) * D + c] = v;
         }
-        later_start |= rv.aux(fs, r, e)[2] > 0.5f;              // (frame f's own flag only matters to the frames older than f)
     }
     // the step OUT of `slot`: its action / reward / done are stored with the NEXT slot; after an auto-reset the true next
     // observation is the terminal row the step kernel put into the chunk's terminal section (row = ticket mod T), unless later
