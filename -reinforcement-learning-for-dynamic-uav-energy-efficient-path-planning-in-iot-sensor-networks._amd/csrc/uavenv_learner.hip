@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include "../../include/uavenv.h"
+#include "uavenv_noise.h"
 
 namespace {
 
@@ -205,6 +206,31 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
     }
 }
 
+// SB3's epsilon-greedy action selection for a vector of environments in one launch (argmax, the coin, the random action):
+// ONE workgroup walks all environments, so that it can also advance the draw counter it keys its Philox words with -- a captured
+// launch then draws fresh numbers at every replay without a second kernel.  shared_coin: SB3's predict() flips ONE coin for the
+// whole vector (the artefact DQNLearner(shared_exploration_coin=True) reproduces); otherwise every environment flips its own.
+__global__ __launch_bounds__(1024) void epsilon_greedy_kernel(const float* __restrict__ q, int32_t n_envs, int32_t n_actions,
+                                                            const float* __restrict__ eps_dev, float* __restrict__ counter_dev, uint64_t seed,
+                                                            int32_t shared_coin, int32_t* __restrict__ actions_out) {
+    const uint64_t cnt = (uint64_t)counter_dev[0];
+    const float eps = eps_dev[0];
+    const uavenv::Words4 w0 = uavenv::philox4x32<UAVENV_PHILOX_ROUNDS>(0xFFFFFFFFu, (uint32_t)cnt, (uint32_t)(cnt >> 32), 0x45505347u /* "EPSG" */,
+                                                                      (uint32_t)seed, (uint32_t)(seed >> 32));
+    for (int e = threadIdx.x; e < n_envs; e += blockDim.x) {
+        const float* row = q + (size_t)e * n_actions;
+        int best = 0; float bv = row[0];
+        for (int a = 1; a < n_actions; a++) { const float v = row[a]; if (v > bv) { bv = v; best = a; } }      // first maximum, like torch.argmax
+        const uavenv::Words4 w = uavenv::philox4x32<UAVENV_PHILOX_ROUNDS>((uint32_t)e, (uint32_t)cnt, (uint32_t)(cnt >> 32), 0x45505347u,
+                                                                         (uint32_t)seed, (uint32_t)(seed >> 32));
+        const float coin = uavenv::u24(shared_coin ? w0.w0 : w.w0);
+        const int rnd = (int)uavenv::mulhi32(w.w1, (uint32_t)n_actions);
+        actions_out[e] = coin < eps ? rnd : best;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) counter_dev[0] = (float)(cnt + 1);
+}
+
 }  // namespace
 
 // replaces: the three matrix products of torch.nn.Linear's forward / backward at DQN batch sizes (dqn.py:1086 batch_size 256).
@@ -256,5 +282,16 @@ extern "C" int uavenv_clip_adam(float* param_dev, const float* grad_dev, float* 
     const unsigned blocks = (unsigned)((n + 256 * 4 - 1) / (256 * 4) < 2048 ? (n + 256 * 4 - 1) / (256 * 4) : 2048);
     clip_adam_kernel<<<dim3(blocks), dim3(kNormBlocks), 0, (hipStream_t)stream>>>(param_dev, grad_dev, exp_avg_dev, exp_avg_sq_dev, n, scalars_dev,
                                                                                workspace_dev, max_norm, beta1, beta2, eps);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_E_HIP;
+}
+
+// replaces: the action selection of SB3's DQN at collect time (predict(): argmax Q with probability 1 - epsilon, else a uniform
+// action) for a vector of environments: q_dev float [n_envs][n_actions], *eps_dev the exploration rate, *counter_dev a float the
+// kernel advances by one per call (the Philox counter of its draws, with `seed`), actions_out_dev int32 [n_envs].
+extern "C" int uavenv_epsilon_greedy(const float* q_dev, int32_t n_envs, int32_t n_actions, const float* eps_dev, float* counter_dev,
+                                     uint64_t seed, int32_t shared_coin, int32_t* actions_out_dev, void* stream) {
+    if (!q_dev || !eps_dev || !counter_dev || !actions_out_dev || n_envs < 1 || n_actions < 1) return UAVENV_E_INVALID;
+    epsilon_greedy_kernel<<<dim3(1), dim3(1024), 0, (hipStream_t)stream>>>(q_dev, n_envs, n_actions, eps_dev, counter_dev, seed, shared_coin,
+                                                                        actions_out_dev);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_E_HIP;
 }

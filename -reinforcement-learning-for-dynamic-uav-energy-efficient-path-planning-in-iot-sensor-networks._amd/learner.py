@@ -253,8 +253,30 @@ class DQNLearner:
         self.ring.commit(z, z, z)                                  # slot 0: the reset observation (no incoming transition)
         self._stacked = self.fs.reset(obs)
 
+    def _select_actions(self, qvalues, eps_dev):
+        """epsilon-greedy over a vector of Q-values in ONE launch (uavenv_epsilon_greedy): argmax, coin, random action; the draw
+        counter lives on the device and is advanced by the kernel, so eager calls and graph replays draw the same sequence."""
+        import ctypes as C
+        if self.__dict__.get("_act_out") is None:
+            self._act_out = torch.zeros(self.E, dtype=torch.int32, device=self.dev)
+            self._act_counter = torch.zeros(1, dtype=torch.float32, device=self.dev)
+            self._alib = N.lib()
+        q = qvalues.contiguous()
+        rc = self._alib.uavenv_epsilon_greedy(C.c_void_p(q.data_ptr()), self.E, q.shape[1], C.c_void_p(eps_dev.data_ptr()),
+                                              C.c_void_p(self._act_counter.data_ptr()), (self._sample_seed * 2654435761 + 97) & 0xFFFFFFFFFFFFFFFF,
+                                              1 if self.shared_coin else 0, C.c_void_p(self._act_out.data_ptr()),
+                                              C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream))
+        if rc:
+            raise RuntimeError(f"uavenv_epsilon_greedy failed ({rc})")
+        return self._act_out
+
     @torch.no_grad()
     def act(self, stacked, epsilon):
+        if self.dev.type == "cuda":
+            if self.__dict__.get("_eps_eager") is None:
+                self._eps_eager = torch.zeros((), device=self.dev)
+            self._eps_eager.fill_(float(epsilon))
+            return self._select_actions(self.q(stacked), self._eps_eager)
         greedy = self.q(stacked).argmax(1).to(torch.int32)
         if epsilon <= 0.0:
             return greedy
@@ -314,10 +336,7 @@ class DQNLearner:
                 g.capture_begin(pool=pool)
                 try:
                     ring._point_env(slot)
-                    greedy = q_values(self.fs.stacked).argmax(1).to(torch.int32)
-                    rnd = torch.randint(0, 5, (E,), device=self.dev, dtype=torch.int32, generator=self.gen)
-                    coin = torch.rand(1 if self.shared_coin else E, device=self.dev, generator=self.gen)
-                    actions = torch.where(coin < self._g_eps, rnd, greedy)
+                    actions = self._select_actions(q_values(self.fs.stacked), self._g_eps)
                     o, _, d = self.env.step(actions, obs_out=ring.local_obs_slot(slot))
                     self.fs.step(o, d, None)
                     if self.target_every == 1:
@@ -325,7 +344,7 @@ class DQNLearner:
                 finally:
                     g.capture_end()
                 graphs[slot] = g
-                del greedy, rnd, coin, actions, o, d
+                del actions, o, d
         torch.cuda.current_stream(self.dev).wait_stream(side)
         ring._point_env()                # capturing executed nothing
         self._act_graphs = graphs

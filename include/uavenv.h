@@ -370,6 +370,13 @@ int uavenv_td_loss(const float* q_dev, const float* q_next_dev, const int64_t* a
 int uavenv_clip_adam(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n,
                      float* scalars_dev, float* workspace_dev, float max_norm, float beta1, float beta2, float eps, void* stream);
 
+/* replaces: the action selection of SB3's DQN while collecting (argmax Q with probability 1 - epsilon, else a uniform action) for
+ * a vector of environments, one launch instead of six: q_dev float [n_envs][n_actions], *eps_dev the exploration rate, *counter_dev
+ * a float that the kernel advances by one per call (it keys the Philox draws together with `seed`, so a captured launch draws fresh
+ * numbers at every replay), actions_out_dev int32 [n_envs].  shared_coin != 0: ONE coin for the whole vector, as SB3's predict(). */
+int uavenv_epsilon_greedy(const float* q_dev, int32_t n_envs, int32_t n_actions, const float* eps_dev, float* counter_dev,
+                          uint64_t seed, int32_t shared_coin, int32_t* actions_out_dev, void* stream);
+
 /* ---- state access (checkpoint / parity / the attribute reads of SURVEY 1) -------------------- */
 /* Copies one whole field.  `bytes` must equal the field size; dst/src may be host or device.
  * A state handed to uavenv_set_state must be one the library could have produced: 0 <= data_buffer <= max_buffer_size in every

@@ -123,11 +123,29 @@ def test_config3_learner_4096x50_graph_path_equals_eager_and_oracle(extractor, n
     loss = LR.td_loss(q0, t0, batch, Lg.gamma, Lg.reward_scale)
     opt0.zero_grad(set_to_none=True)
     loss.backward()
+    raw = [w.grad.detach().clone() for w in q0.parameters()]
     torch.nn.utils.clip_grad_norm_(q0.parameters(), Lg.max_grad_norm)
     opt0.step()
     assert float(loss.detach()) == pytest.approx(float(Lg.last_loss), rel=1e-4)
-    for p, w in zip(Lg.q.parameters(), q0.parameters()):
-        assert torch.allclose(p.detach(), w.detach(), rtol=1e-4, atol=1e-6), float((p.detach() - w.detach()).abs().max())
+    # (1) the GRADIENTS of the captured update against the hand-made ones: the well-conditioned comparison, possible where the update
+    #     keeps them in a buffer of its own (the library's update; the PyTorch update's gradient tensors live in the graph's pool and
+    #     are recycled by later nodes of the same graph)
+    if Lg._mlp is not None:
+        got = [t for pair in zip(Lg._mlp.gw, Lg._mlp.gb) for t in pair]
+        gmax = max(float(w.abs().max()) for w in raw)
+        for (name, _), g_, w_ in zip(Lg.q.named_parameters(), got, raw):
+            assert float((g_ - w_).abs().max()) <= 2e-4 * max(float(w_.abs().max()), 1e-3 * gmax), (name, float((g_ - w_).abs().max()))
+    # (2) the PARAMETERS after Adam: its step is lr * m / (sqrt(v) + 1e-8), and where gradients are cancellation noise (the attention's
+    #     in-projection biases: 1e-7 out of summands of 1e-3; the key bias is exactly zero in theory) last-bit differences between graph
+    #     replay and eager launches become visible fractions of lr.  Every element must stay within a step; the well-conditioned
+    #     statement is about what the network computes: the two updated networks agree on the Q-values of the batch.
+    lr_now = Lg.lr_schedule(Lg.progress_remaining())
+    for (name, p), w in zip(Lg.q.named_parameters(), q0.parameters()):
+        diff = (p.detach() - w.detach()).abs()
+        assert float(diff.max()) <= 2.0 * lr_now, (name, float(diff.max()), lr_now)
+    with torch.no_grad():
+        qa, qb = Lg.q(batch["obs"]), q0(batch["obs"])
+    assert torch.allclose(qa, qb, rtol=1e-3, atol=1e-3 * float(qb.abs().max())), float((qa - qb).abs().max())
     _oracle_replay_of_ring(O, rg, over, [0, 1, 63, 64, 1000, 2047, 2048, 4095], steps)
     if extractor == "attention":
         assert Lg._fused is not None
