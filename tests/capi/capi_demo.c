@@ -33,7 +33,15 @@ int main(int argc, char** argv) {
     for (int i = 0; i < E * D; i++) osum += obs[i];
     act[0] = 9;                                            /* invalid action: reported, not fatal */
     rc = uavenv_step_host(env, act, obs, rew, done, NULL);
-    printf("obs_dim=%d reward_sum=%.9f obs_sum=%.6f dones=%ld invalid_rc=%d\n", D, sum, osum, dones, rc);
+    /* constants of the live handle: read back, a legal change, an illegal one (buffer sizes are fixed at create) */
+    UavEnvConfig live;
+    int rc_get = uavenv_get_config(env, &live);
+    int same = live.num_sensors == 20 && live.duty_cycle == 60.0 && live.seed == 99;
+    live.shadowing_std_db = 0.0;
+    int rc_set = uavenv_set_config(env, &live);
+    live.num_sensors = 21;
+    int rc_bad = uavenv_set_config(env, &live);
+    printf("obs_dim=%d reward_sum=%.9f obs_sum=%.6f dones=%ld invalid_rc=%d config=%d/%d/%d/%d\n", D, sum, osum, dones, rc, rc_get, same, rc_set, rc_bad);
     uavenv_destroy(env);
     free(obs); free(rew); free(done); free(act);
     return 0;

@@ -20,8 +20,9 @@ def test_plain_c_program_through_the_abi(tmp_path):
                            os.path.join(ROOT, "tests", "capi", "capi_demo.c"), "-L", PKG, "-luavenv_hip",
                            "-Wl,-rpath," + PKG])
     out = subprocess.check_output([exe, "8", "25"], text=True)
-    m = re.search(r"obs_dim=(\d+) reward_sum=([-\d.]+) obs_sum=([-\d.]+) dones=(\d+) invalid_rc=(-?\d+)", out)
+    m = re.search(r"obs_dim=(\d+) reward_sum=([-\d.]+) obs_sum=([-\d.]+) dones=(\d+) invalid_rc=(-?\d+) config=(-?\d+)/(\d)/(-?\d+)/(-?\d+)", out)
     assert m, out
+    assert [int(m.group(i)) for i in (6, 7, 8, 9)] == [0, 1, 0, -1]      # uavenv_get_config / set_config: ok, values read back, ok, UAVENV_E_INVALID
     E, steps = 8, 25
     env = U.BatchedUAVEnv(E, num_sensors=20, grid_size=(200, 200), max_steps=10, duty_cycle=60.0, seed=99)
     env.reset()
