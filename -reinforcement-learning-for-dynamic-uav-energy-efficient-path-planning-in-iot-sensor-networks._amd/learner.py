@@ -149,7 +149,7 @@ class DQNLearner:
                  target_update_interval=5_000, train_freq=4, gradient_steps=1, net_arch=(512, 512, 256), n_stack=4,
                  total_timesteps=3_000_000, max_grad_norm=10.0, extractor="mlp", shared_exploration_coin=False, seed=0,
                  chunk_len=None, reward_scale=1.0, use_graphs=None, tune_gemms=None, frame_stack_cls=FrameStack,
-                 updates_per_transition=None, fused_update=None):
+                 updates_per_transition=None, fused_update=None, replicate_replay=True):
         """reward_scale (not an SB3 / reference option; default 1.0 = theirs): the environment's rewards reach 1e4-1e5 per
         step (+5000 per new sensor, 100 x bytes x urgency), which a smooth-L1 loss follows at one unit of gradient per
         sample -- the reference spends 750 k gradient steps on it.  Short runs (the tests) scale the reward in the loss."""
@@ -231,7 +231,17 @@ class DQNLearner:
         slots = max(int(buffer_size) // self.n_envs_total, self.k + 2)
         L = int(chunk_len) if chunk_len else max(1, min(64, slots // 4))
         capacity = (math.ceil(slots / L) + 1) * L
-        self.ring = TransitionRing(capacity, self.E, self.D, self.dev, world_size=self.world, rank=self.rank, chunk_len=L)
+        # replicate_replay (several ranks): True = the north star's shared buffer, every rank holds every rank's transitions (one
+        # all-gather per chunk: 2.57 MB per rank and step at 4096 x 50, the xGMI links bound the step rate);
+        # False = every rank keeps ITS OWN transitions only and draws its batch_size / world samples from them -- with the
+        # gradients averaged, an update then sees a STRATIFIED uniform sample of the union of the buffers (same expectation as
+        # uniform sampling from a shared buffer, lower variance) and no transition ever crosses a link: the only collective left is
+        # the gradient all-reduce.  The buffer holds buffer_size transitions in all either way.
+        self.replicate_replay = bool(replicate_replay) or self.world == 1
+        if self.replicate_replay:
+            self.ring = TransitionRing(capacity, self.E, self.D, self.dev, world_size=self.world, rank=self.rank, chunk_len=L)
+        else:
+            self.ring = TransitionRing(capacity, self.E, self.D, self.dev, world_size=1, rank=0, chunk_len=L)
         self.ring.attach(env)
         self.fs = frame_stack_cls(self.E, self.D, self.k, self.dev)
         self.num_timesteps, self.n_calls, self.n_updates = 0, 0, 0

@@ -61,7 +61,7 @@ def test_q_network_shapes_follow_sb3_mlp_policy_and_the_attention_extractor():
 # ---------------------------------------------------------------------------------------------------------------
 # several ranks (BASELINE config 4 as a training run), on CPU over gloo with the doubles of tests/learner_doubles.py
 # ---------------------------------------------------------------------------------------------------------------
-def _learner_worker(rank, world, port, q):
+def _learner_worker(rank, world, port, q, replicate=True):
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -77,7 +77,7 @@ def _learner_worker(rank, world, port, q):
     env = ToyEnv(E, D, rank=rank, period=7)
     L = LR.DQNLearner(env, learning_rate=1e-2, buffer_size=2 * E * 40, batch_size=32, gamma=0.9, learning_starts=0,
                       target_update_interval=2 * E * 6, train_freq=4, gradient_steps=1, net_arch=(16, 8), n_stack=k,
-                      total_timesteps=10**6, seed=11, chunk_len=4, frame_stack_cls=TorchFrameStack)
+                      total_timesteps=10**6, seed=11, chunk_len=4, frame_stack_cls=TorchFrameStack, replicate_replay=replicate)
     ok = L.world == world and L.local_batch == 32 // world and L.n_envs_total == E * world and not L._graphs_usable()
     init = [p.detach().clone() for p in L.q.parameters()]
     L.learn(total_timesteps=2 * E * 4 * 7)                 # 7 rollouts of 4 vector steps; updates start once k + 2 slots are visible
@@ -90,6 +90,16 @@ def _learner_worker(rank, world, port, q):
     ok &= any(not torch.equal(a, b.detach()) for a, b in zip(init, L.q.parameters()))
     # (2) the ranks drew DIFFERENT batches (own generators) of batch_size / world transitions each
     ok &= L.gen.initial_seed() == 11 * 7919 + 13 + rank
+    if not replicate:
+        # (3') rank-local replay: nothing but this rank's own transitions in its ring, no exchange -- and still identical replicas
+        ring = L.ring
+        ok &= ring.world == 1 and not ring.exchange
+        b = ring.sample_stacked(300, k, generator=torch.Generator().manual_seed(3))
+        ok &= bool((torch.floor(b["obs"][:, -D] / 1000) == rank).all()) and bool(b["done"].any()) and bool(b["valid"].all())
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, bool(ok)))
+        return
     # (3) this rank's ring holds the other rank's transitions, episode ends with their terminal rows included
     ring, other = L.ring, 1 - rank
     L.ring.drain()
@@ -119,14 +129,16 @@ def _learner_worker(rank, world, port, q):
     q.put((rank, bool(ok)))
 
 
-def test_two_rank_learner_keeps_replicas_identical_and_shares_the_ring():
+@pytest.mark.parametrize("replicate", [True, False], ids=["shared_ring_allgather", "rank_local_rings"])
+def test_two_rank_learner_keeps_replicas_identical_and_shares_the_ring(replicate):
     """BASELINE config 4 as training: each rank steps its shard, the ring all-gathers chunks (terminal sections included),
-    every rank draws batch_size / world samples, ONE flat all-reduce averages the gradients: identical weights everywhere."""
+    every rank draws batch_size / world samples, ONE flat all-reduce averages the gradients: identical weights everywhere.
+    replicate_replay=False: no transition crosses ranks (stratified sampling of the union of the rank-local buffers)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_learner_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 31500 + (os.getpid() % 2000) + (0 if replicate else 7)
+    procs = [ctx.Process(target=_learner_worker, args=(r, 2, port, q, replicate)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
