@@ -286,6 +286,8 @@ def oracle_config(case, seed, grids):
         over["duty_cycle"] = kw.pop("sensor_duty_cycle")
     kw.pop("path_loss_exponent", None)                       # carried by IoTSensor, read by nothing on the path
     kw.pop("render_mode", None)
+    if "include_sensor_positions" in kw:
+        kw["include_sensor_positions"] = int(bool(kw["include_sensor_positions"]))
     over.update(kw)
     return O.default_config(**over)
 
@@ -308,6 +310,9 @@ CASES = [
     dict(name="domainrand_s4_n10", n=10, stage=4, steps=320, base=_base(max_steps=150)),
     dict(name="domainrand_s4_n20", n=20, stage=4, steps=320, base=_base(max_steps=110, sensor_duty_cycle=60.0)),
     dict(name="domainrand_s4_n40", n=40, stage=4, steps=240, base=_base(max_steps=75)),
+    # five features per sensor (uav_env.py:286 include_sensor_positions: relative positions in the observation), padded to 253
+    dict(name="domainrand_s2_n20_fps5", n=20, stage=2, steps=240, base=_base(max_steps=80, include_sensor_positions=True, sensor_duty_cycle=40.0)),
+    dict(name="domainrand_s4_n10_fps5", n=10, stage=4, steps=240, base=_base(max_steps=100, include_sensor_positions=True)),
     # battery-limited episodes (uav.py:224: truncation at 2 % of the capacity) instead of the step limit
     dict(name="domainrand_s3_n30_lowbatt", n=30, stage=3, steps=260, base=_base(max_battery=12.0, sensor_duty_cycle=80.0)),
 ]
@@ -345,7 +350,8 @@ def record(case, seed, env_index):
             ep_pos.append(np.stack([rs["pos_x"], rs["pos_y"]], -1)); ep_reset_obs.append(ro)
             return None
 
-        assert ref.env.observation_space.shape == (orc.obs_dim,) == (153,)
+        fps = 5 if case["base"].get("include_sensor_positions") else 3
+        assert ref.env.observation_space.shape == (orc.obs_dim,) == (3 + 50 * fps,)
         bad = open_episode()
         if bad:
             return fail("first reset", bad)

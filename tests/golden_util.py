@@ -38,6 +38,8 @@ def domainrand_overrides(meta):
         over["duty_cycle"] = kw.pop("sensor_duty_cycle")
     kw.pop("path_loss_exponent", None)      # carried by IoTSensor, read by nothing on the path
     kw.pop("render_mode", None)
+    if "include_sensor_positions" in kw:
+        kw["include_sensor_positions"] = int(bool(kw["include_sensor_positions"]))
     over.update(kw)
     return over
 

@@ -76,7 +76,8 @@ def test_hip_replays_real_domainrand(name, auto_reset):
     meta = fx["meta"]
     n, E, k = meta["n"], 3, 1
     env = U.BatchedUAVEnv(E, auto_reset=auto_reset, env_index_base=meta["env_index"] - k, **G.domainrand_overrides(meta))
-    assert env.lane_stride == (16 if n <= 16 else 32 if n <= 32 else 64) and env.obs_dim == 153
+    fps = 5 if meta["base"].get("include_sensor_positions") else 3
+    assert env.lane_stride == (16 if n <= 16 else 32 if n <= 32 else 64) and env.obs_dim == 3 + 50 * fps
     dev = env.device
     ep = 0
 
@@ -127,7 +128,7 @@ def test_hip_replays_real_domainrand(name, auto_reset):
     env.close()
 
 
-@pytest.mark.parametrize("name", ["domainrand_s2_n20", "domainrand_s4_n40", "domainrand_s3_n30_lowbatt"])
+@pytest.mark.parametrize("name", ["domainrand_s2_n20", "domainrand_s4_n40", "domainrand_s3_n30_lowbatt", "domainrand_s2_n20_fps5"])
 def test_gym_domainrand_env_matches_the_real_class(name):
     """The single-environment mirror (`gym_env.DomainRandEnv`, the reference's own constructor and call sequence):
     reset() / step() values and `last_episode_stats` as the real class produced them."""
@@ -136,7 +137,7 @@ def test_gym_domainrand_env_matches_the_real_class(name):
     meta = fx["meta"]
     env = U.DomainRandEnv(fixed_num_sensors=meta["n"], curriculum_stage=meta["stage"], base_config=meta["base"],
                           seed=meta["seed"], env_index=meta["env_index"])
-    assert env.observation_space.shape == (153,) and env.last_episode_stats is None
+    assert env.observation_space.shape == (253 if meta["base"].get("include_sensor_positions") else 153,) and env.last_episode_stats is None
     ep = 0
     obs, _ = env.reset()
     assert np.array_equal(obs, fx["ep_reset_obs"][0])

@@ -120,9 +120,9 @@ def test_oracle_policies_replay_reference_agents(name):
 # ---------------------------------------------------------------------------------------------------------------
 def test_domainrand_fixtures_present():
     names = G.domainrand_fixture_names()
-    assert len(names) >= 10
+    assert len(names) >= 12
     finished = sum(int(G.load(n)["truncated"].sum()) for n in names)
-    assert finished >= 20                      # every fixture holds >= 2 finished episodes
+    assert finished >= 24                      # every fixture holds >= 2 finished episodes
 
 
 def check_domainrand_stats(got, row, keys, rtol=1e-12):
