@@ -31,8 +31,20 @@ constexpr int kMaxStack = 16;
 // sampleable slot has no successor yet), rank uniform on the ranks, environment uniform on a rank's environments.
 struct RingDraw { const int64_t* window; const float* counter; uint64_t seed; int64_t* index_out; };
 
-// one wavefront per sample; everything about the sample is wave-uniform, the lanes copy row elements
-template <bool kDraw>
+// a position in the ring as (chunk, block within the chunk): stepping to the neighbouring slot is an add and a wrap, where
+// slot / L and slot % L per frame were a 64-bit division each (~130 instructions; the kernel had 2 (k + 2) of them)
+struct RingPos {
+    int chunk, blk;
+    __device__ __forceinline__ void back(const UavRingLayout& g) { if (--blk < 0) { blk = g.slots_per_chunk - 1; chunk = chunk == 0 ? g.num_chunks - 1 : chunk - 1; } }
+    __device__ __forceinline__ void forward(const UavRingLayout& g) { if (++blk == g.slots_per_chunk) { blk = 0; chunk = chunk + 1 == g.num_chunks ? 0 : chunk + 1; } }
+};
+
+// one wavefront per sample; everything about the sample is wave-uniform, the lanes copy row elements.  KB: compile-time bound of
+// the stack depth k, so that the rows of a sample live in registers: EVERY load of the sample (k episode-start flags, k + 1 rows,
+// the successor's aux words, the chunk's terminal count) depends on (slot, rank, env) only and is issued before the first wait --
+// one trip to HBM per sample (the ring is far larger than the L2s: every row is a miss) where the loop form the compiler made of
+// `for f: load, multiply, store` paid k + 3 of them in a row (11 us for 256 samples x 4 frames).
+template <bool kDraw, int KB>
 __global__ __launch_bounds__(256) void uav_ring_gather_kernel(RingView rv, const int64_t* __restrict__ age, const int64_t* __restrict__ slot_,
                                                               const int64_t* __restrict__ rank_, const int64_t* __restrict__ env_, RingDraw dr,
                                                               int32_t batch,
@@ -40,7 +52,7 @@ __global__ __launch_bounds__(256) void uav_ring_gather_kernel(RingView rv, const
                                                               int64_t* __restrict__ action_out, float* __restrict__ reward_out,
                                                               uint8_t* __restrict__ done_out, uint8_t* __restrict__ valid_out) {
     const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // (tells the compiler it is wave-uniform: addresses in SGPRs)
     if (b >= batch) return;
     const UavRingLayout& g = rv.g;
     const long cap = (long)g.num_chunks * g.slots_per_chunk;
@@ -53,7 +65,8 @@ __global__ __launch_bounds__(256) void uav_ring_gather_kernel(RingView rv, const
         j = (long)(((uint64_t)w.w0 * (uint64_t)(n - 1)) >> 32);
         r = (long)mulhi32(w.w1, (uint32_t)g.world);
         e = (long)mulhi32(w.w2, (uint32_t)g.envs);
-        slot = (oldest + j) % cap;
+        slot = oldest + j;                                     // oldest < cap, j < cap
+        if (slot >= cap) slot -= cap;
         if (lane == 0 && dr.index_out != nullptr) {
             dr.index_out[b] = j; dr.index_out[batch + b] = slot; dr.index_out[2 * (long)batch + b] = r; dr.index_out[3 * (long)batch + b] = e;
         }
@@ -61,47 +74,113 @@ __global__ __launch_bounds__(256) void uav_ring_gather_kernel(RingView rv, const
         j = age[b]; slot = slot_[b]; r = rank_[b]; e = env_[b];
     }
     const int D = g.obs_dim;
+    const long row_off = e * D, aux_off = g.obs_floats + e * 4;
+    auto block_of = [&](const RingPos& p) { return rv.store + ((long)p.chunk * g.world + r) * g.section + (long)p.blk * g.block; };
+    RingPos at{(int)((unsigned)slot / (unsigned)g.slots_per_chunk), 0};
+    at.blk = (int)slot - at.chunk * g.slots_per_chunk;
     // frame f (0 = oldest) sits k-1-f slots behind `slot`; it belongs to the transition's episode iff no LATER frame of the
     // stack is the first observation of an episode (aux.done of a slot: the step INTO it ended one) and the ring reaches back
-    // that far (age j counts slots from the oldest sampleable one).  All k episode-start flags are fetched first (lane f reads
-    // frame f's), so that the row copies below are independent loads instead of a chain of k dependent ones.
-    float* orow = obs_out + (size_t)b * k * D;
-    float* nrow = next_out + (size_t)b * k * D;
-    float start_flag = 0.0f;
-    if (lane < k) start_flag = rv.aux(((((slot - (k - 1 - lane)) % cap) + cap) % cap), r, e)[2];
-    const unsigned long long starts = __ballot(start_flag > 0.5f);            // bit f: frame f is the first of an episode
-#pragma unroll 4
-    for (int f = 0; f < k; f++) {
-        const long back = k - 1 - f;
-        const long fs = (((slot - back) % cap) + cap) % cap;
-        const bool later_start = (starts >> (f + 1)) != 0ull;                 // (frame f's own flag only matters to the frames older than f)
-        const float keep = (!later_start && (j - back) >= 0) ? 1.0f : 0.0f;
-        const float* src = rv.obs(fs, r, e);
-        for (int c = lane; c < D; c += 64) {
-            const float v = src[c] * keep;                     // (a product like the tensor expression: keeps the sign of a zero)
-            orow[f * D + c] = v;
-            if (f >= 1) nrow[(f - 1) * D + c] = v;
-        }
+    // that far (age j counts slots from the oldest sampleable one).
+    const float* blk[KB];                                     // blk[i]: the block of the slot i behind `slot` (frame k-1-i)
+    {
+        RingPos p = at;
+#pragma unroll
+        for (int i = 0; i < KB; i++) { blk[i] = block_of(p); if (i + 1 < k) p.back(g); }     // (i >= k: repeats the oldest frame's block, never stored)
     }
-    // the step OUT of `slot`: its action / reward / done are stored with the NEXT slot; after an auto-reset the true next
-    // observation is the terminal row the step kernel put into the chunk's terminal section (row = ticket mod T), unless later
-    // episode ends of that chunk have overwritten it (count - ticket > T): then the transition is reported invalid
-    const long nxt = (slot + 1) % cap;
-    const float* ax = rv.aux(nxt, r, e);
-    const bool done = ax[2] > 0.5f;
-    const int32_t ticket = __float_as_int(ax[3]);
-    const float* pt = rv.part(nxt / g.slots_per_chunk, r);
-    const long count = (long)reinterpret_cast<const int32_t*>(pt)[g.count_off];
+    RingPos nx = at;
+    nx.forward(g);
+    const float* nblk = block_of(nx);
+    // ---- all loads -------------------------------------------------------------------------------------------------------
+    // the sample's small words in ONE vector load (a scalar load per word would be waited for one at a time, ahead of the rows):
+    // lane i < KB: aux.done of the slot i behind `slot` (is it the first observation of an episode?); lanes 16..19: the successor's
+    // aux words -- the step OUT of `slot` keeps its action / reward / done / ticket with the NEXT slot; lane 20: the terminal count
+    // of the successor's chunk
+    const float* pt = rv.store + ((long)nx.chunk * g.world + r) * g.section;
+    const float* q = blk[0] + aux_off + 2;
+#pragma unroll
+    for (int i = 1; i < KB; i++) if (lane == i) q = blk[i] + aux_off + 2;
+    if (lane >= 16 && lane < 20) q = nblk + aux_off + (lane - 16);
+    if (lane == 20) q = pt + g.count_off;
+    float v[KB + 1][4];
+    auto load_rows = [&](int c0) {
+        int cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int c = c0 + lane + 64 * u; cc[u] = c < D ? c : D - 1; }      // clamped: loads need no branch
+#pragma unroll
+        for (int i = 0; i < KB; i++) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[i][u] = blk[i][row_off + cc[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[KB][u] = nblk[row_off + cc[u]];
+    };
+    auto store_rows = [&](int c0, unsigned long long starts) {
+#pragma unroll
+        for (int i = 0; i < KB; i++) {
+            if (i < k) {
+                const int f = k - 1 - i;
+                // a LATER frame (a smaller i) starting an episode cuts frame f off; frame f's own flag only matters to older frames
+                const bool later_start = (starts & ((1ull << i) - 1ull)) != 0ull;
+                const float keep = (!later_start && (j - i) >= 0) ? 1.0f : 0.0f;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int c = c0 + lane + 64 * u;
+                    if (c < D) {
+                        const float val = v[i][u] * keep;          // (a product like the tensor expression: keeps the sign of a zero)
+                        obs_out[((size_t)b * k + f) * D + c] = val;
+                        if (f >= 1) next_out[((size_t)b * k + f - 1) * D + c] = val;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int c = c0 + lane + 64 * u;
+            if (c < D) next_out[((size_t)b * k + k - 1) * D + c] = v[KB][u];
+        }
+    };
+    // the first 256 floats of every row (all of it for the reference's 153 or 253), THEN the small words, in program order: the
+    // first wait is for everything at once.  (With the rows inside a loop over passes, the compiler hoists the episode-boundary
+    // ballot -- and the wait for the small words -- in front of the loop, i.e. in front of the row loads.)
+    load_rows(0);
+    const float meta = *q;
+    // (an unconditional use of every row word here: without it the compiler sinks the successor row's loads into the guarded
+    //  stores at the end, behind the wait for the small words -- a second trip to memory)
+#pragma unroll
+    for (int i = 0; i <= KB; i++) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) asm volatile("" : "+v"(v[i][u]));
+    }
+    const unsigned long long starts = __ballot(meta > 0.5f) & ((1ull << k) - 1ull);       // bit i: the slot i behind is an episode's first
+    store_rows(0, starts);
+    for (int c0 = 256; c0 < D; c0 += 256) { load_rows(c0); store_rows(c0, starts); }
+    // the newest frame of next_obs is the successor slot's row -- written above unconditionally -- except after an auto-reset (about
+    // one sample in an episode's length): then it is the terminal row the step kernel put into the chunk's terminal section
+    // (row = ticket mod T), copied over it, unless later episode ends of that chunk have overwritten that (count - ticket > T):
+    // then the transition is reported invalid
+    const int meta_bits = __float_as_int(meta);
+    const float ax_action = __int_as_float(__builtin_amdgcn_readlane(meta_bits, 16)), ax_reward = __int_as_float(__builtin_amdgcn_readlane(meta_bits, 17));
+    const bool done = __int_as_float(__builtin_amdgcn_readlane(meta_bits, 18)) > 0.5f;
+    const int32_t ticket = __builtin_amdgcn_readlane(meta_bits, 19);
+    const long count = (long)__builtin_amdgcn_readlane(meta_bits, 20);
     const bool have_term = done && ticket >= 0 && (count - (long)ticket) <= (long)g.terminal_rows;
-    const long row = (long)(ticket < 0 ? 0 : ticket) % g.terminal_rows;
-    const float* last = have_term ? pt + g.term_off + row * D : rv.obs(nxt, r, e);
-    for (int c = lane; c < D; c += 64) nrow[(k - 1) * D + c] = last[c];
+    if (have_term) {                                          // wave-uniform
+        const float* last = pt + g.term_off + (long)(ticket % g.terminal_rows) * D;
+        for (int c = lane; c < D; c += 64) next_out[((size_t)b * k + k - 1) * D + c] = last[c];
+    }
     if (lane == 0) {
-        action_out[b] = (int64_t)ax[0];
-        reward_out[b] = ax[1];
+        action_out[b] = (int64_t)ax_action;
+        reward_out[b] = ax_reward;
         done_out[b] = done ? 1 : 0;
         valid_out[b] = (!done || have_term) ? 1 : 0;
     }
+}
+
+template <bool kDraw, typename... A>
+void launch_gather(int k, dim3 grid, hipStream_t s, A... a) {
+    if (k <= 4) uav_ring_gather_kernel<kDraw, 4><<<grid, dim3(256), 0, s>>>(a...);
+    else if (k <= 10) uav_ring_gather_kernel<kDraw, 10><<<grid, dim3(256), 0, s>>>(a...);
+    else uav_ring_gather_kernel<kDraw, kMaxStack><<<grid, dim3(256), 0, s>>>(a...);
 }
 
 }  // namespace uavenv
@@ -118,7 +197,7 @@ extern "C" int uavenv_ring_gather_stacked(const float* store_dev, const UavRingL
         g.term_off < g.slots_per_chunk * g.block || g.count_off < g.term_off + g.terminal_rows * g.obs_dim || g.section <= g.count_off)
         return UAVENV_E_INVALID;
     uavenv::RingView rv{store_dev, g};
-    uavenv::uav_ring_gather_kernel<false><<<dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(
+    uavenv::launch_gather<false>(num_frames, dim3((unsigned)((batch + 3) / 4)), (hipStream_t)stream,
         rv, age_dev, slot_dev, rank_dev, env_dev, uavenv::RingDraw{nullptr, nullptr, 0, nullptr}, batch, num_frames, obs_out_dev, next_obs_out_dev,
         action_out_dev, reward_out_dev, done_out_dev, valid_out_dev);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_E_HIP;
@@ -141,8 +220,8 @@ extern "C" int uavenv_ring_sample_stacked(const float* store_dev, const UavRingL
         g.term_off < g.slots_per_chunk * g.block || g.count_off < g.term_off + g.terminal_rows * g.obs_dim || g.section <= g.count_off)
         return UAVENV_E_INVALID;
     uavenv::RingView rv{store_dev, g};
-    uavenv::uav_ring_gather_kernel<true><<<dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(
-        rv, nullptr, nullptr, nullptr, nullptr, uavenv::RingDraw{window_dev, counter_dev, seed, index_out_dev}, batch, num_frames, obs_out_dev,
+    uavenv::launch_gather<true>(num_frames, dim3((unsigned)((batch + 3) / 4)), (hipStream_t)stream,
+        rv, (const int64_t*)nullptr, (const int64_t*)nullptr, (const int64_t*)nullptr, (const int64_t*)nullptr, uavenv::RingDraw{window_dev, counter_dev, seed, index_out_dev}, batch, num_frames, obs_out_dev,
         next_obs_out_dev, action_out_dev, reward_out_dev, done_out_dev, valid_out_dev);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_E_HIP;
 }

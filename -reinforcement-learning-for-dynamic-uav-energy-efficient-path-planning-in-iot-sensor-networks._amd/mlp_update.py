@@ -54,7 +54,10 @@ class FusedMLPUpdate:
         K0 = self.layers[0].in_features
         outs = [m.out_features for m in self.layers]
         act = self.B * sum(outs)
-        self.work = torch.zeros(self.n_params + 2 * act + self.B * sum(outs[:-1]) + self.B * outs[-1], **f32)
+        # (the activations start on a 256-byte boundary: the products read rows four floats at a time only from 16-byte aligned
+        # addresses, and the parameter count of the reference network is odd)
+        act0 = -(-self.n_params // 64) * 64
+        self.work = torch.zeros(act0 + 2 * act + self.B * sum(outs[:-1]) + self.B * outs[-1], **f32)
         self.norm_workspace = torch.zeros(N.UPD_WORKSPACE, **f32)
         z = self.work
         self.grad = z[:self.n_params]
@@ -71,7 +74,7 @@ class FusedMLPUpdate:
                 (self.wt if name == "weight" else self.bt).append(pt.data)
                 (self.gw if name == "weight" else self.gb).append(self.grad[off:off + n].view_as(p))
                 off += n
-        cur = self.n_params
+        cur = act0
         self.z, self.zt, self.da = [], [], []
         for lst in (self.z, self.zt):                      # pre-activations of the online / the target network
             for o in outs:

@@ -32,7 +32,8 @@ def _gemm(torch, N, A, B, Cm, M, Nn, K, a_sm, a_sk, b_sk, b_sn, flags=0, bias=No
     assert rc == 0, rc
 
 
-@pytest.mark.parametrize("M,Nn,K", [(256, 512, 612), (256, 5, 256), (64, 70, 33), (16, 64, 16), (5, 256, 256), (512, 612, 256), (256, 256, 5)])
+@pytest.mark.parametrize("M,Nn,K", [(256, 512, 612), (256, 5, 256), (64, 70, 33), (16, 64, 16), (5, 256, 256), (512, 612, 256), (256, 256, 5),
+                                    (304, 960, 100)])    # 19 x 15 = 285 tiles: two tiles per workgroup, the last one half idle
 def test_small_batch_gemm_all_three_layouts_match_torch(M, Nn, K):
     torch, U, N, LR, F = _mods()
     g = torch.Generator(device="cuda").manual_seed(M * 1000 + Nn)
