@@ -17,7 +17,14 @@ FLAG_RANDOM_LAYOUT, FLAG_FAR_START, FLAG_PROX_SHAPING, FLAG_JAIN_BONUS, FLAG_AUT
 
 E_INVALID, E_HIP, E_ACTION, E_ALLOC = -1, -2, -3, -4
 POLICY_ACTIONS, POLICY_RANDOM, POLICY_NEAREST, POLICY_MAX_THROUGHPUT_V2 = 0, 1, 2, 3
-GEMM_A_RELU, GEMM_A_MASK, GEMM_B_RELU, GEMM_BIAS, GEMM_ROWSUM = 1, 2, 4, 8, 16
+GEMM_A_RELU, GEMM_A_MASK, GEMM_B_RELU, GEMM_BIAS, GEMM_ROWSUM, GEMM_SUMSQ = 1, 2, 4, 8, 16, 32
+
+
+def gemm_sumsq_count(M, N):
+    """include/uavenv.h:UAVENV_GEMM_SUMSQ_COUNT"""
+    return ((M + 15) // 16) * ((N + 31) // 32)
+
+
 UPD_LOSS, UPD_NORM2, UPD_STEP, UPD_BC1, UPD_BC2, UPD_LR, UPD_COUNT, UPD_WORKSPACE = 0, 1, 2, 3, 4, 5, 8, 256
 ABI_VERSION = 2
 
@@ -83,7 +90,7 @@ class UavGemm(C.Structure):
     """include/uavenv.h:UavGemm (one product of uavenv_gemm_f32)."""
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p), ("a_mask", C.c_void_p), ("row_sum", C.c_void_p),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("flags", C.c_int32),
-                ("a_sm", C.c_int64), ("a_sk", C.c_int64), ("b_sk", C.c_int64), ("b_sn", C.c_int64), ("ldc", C.c_int64)]
+                ("a_sm", C.c_int64), ("a_sk", C.c_int64), ("b_sk", C.c_int64), ("b_sn", C.c_int64), ("ldc", C.c_int64), ("sumsq", C.c_void_p)]
 
 
 EXPORTS = [
@@ -158,7 +165,7 @@ def _load(path):
         "uavenv_attention_features": (C.c_int, [vp, vp, vp, i32, i32, vp]),
         "uavenv_gemm_f32": (C.c_int, [C.POINTER(UavGemm), C.POINTER(UavGemm), vp]),
         "uavenv_td_loss": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp, vp]),
-        "uavenv_clip_adam": (C.c_int, [vp, vp, vp, vp, C.c_int64, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
+        "uavenv_clip_adam": (C.c_int, [vp, vp, vp, vp, C.c_int64, vp, vp, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
         "uavenv_epsilon_greedy": (C.c_int, [vp, i32, i32, vp, vp, u64, i32, vp, vp]),
         "uavenv_frame_stack": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
         "uavenv_ring_gather_stacked": (C.c_int, [vp, C.POINTER(UavRingLayout), vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]),

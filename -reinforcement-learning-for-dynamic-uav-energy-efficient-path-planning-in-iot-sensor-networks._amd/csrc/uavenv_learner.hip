@@ -119,10 +119,15 @@ __global__ __launch_bounds__(1024) void gemm_f32_kernel(GemmArgs g0, GemmArgs g1
         if (gq == 0) red[wave][kTile + r] = rowsum;
     }
     __syncthreads();
+    // UAVENV_GEMM_SUMSQ: the squares of what this tile writes, summed per 32-column group (a 64-column tile is two groups: lanes
+    // 0..31 | 32..63 of every wavefront; a 32-column tile one) -- the gradient norm's partial sums without a launch of their own
+    const bool want_sq = (g.flags & UAVENV_GEMM_SUMSQ) != 0;
+    __shared__ float sqr[16][2];
     for (int h = 0; h < (dual ? 2 : 1); h++) {
         const int t = dual ? 2 * wg + h : wg, w0 = 8 * h, w1 = dual ? w0 + 8 : 16;
         if (t >= ntiles) break;
         const int tm = t % mt, tn = t / mt;
+        float sq = 0.f;
         for (int e = threadIdx.x; e < kTile; e += 1024) {
             float v = 0.f;
             if (dual) {
@@ -133,12 +138,35 @@ __global__ __launch_bounds__(1024) void gemm_f32_kernel(GemmArgs g0, GemmArgs g1
                 for (int w = 0; w < 16; w++) v += red[w][e];
             }
             const int mm = tm * 16 + e / kCols, n = tn * kCols + e % kCols;
-            if (mm < g.M && n < g.N) g.C[(int64_t)mm * g.ldc + n] = v + ((g.flags & UAVENV_GEMM_BIAS) ? g.bias[n] : 0.f);
+            if (mm < g.M && n < g.N) {
+                v += (g.flags & UAVENV_GEMM_BIAS) ? g.bias[n] : 0.f;
+                g.C[(int64_t)mm * g.ldc + n] = v;
+                sq += v * v;
+            }
         }
         if ((g.flags & UAVENV_GEMM_ROWSUM) && tn == 0 && threadIdx.x < 16) {
             float v = 0.f;
             for (int w = w0; w < w1; w++) v += red[w][kTile + threadIdx.x];
-            if (tm * 16 + (int)threadIdx.x < g.M) g.row_sum[tm * 16 + threadIdx.x] = v;
+            if (tm * 16 + (int)threadIdx.x < g.M) { g.row_sum[tm * 16 + threadIdx.x] = v; sq += v * v; }
+        }
+        if (want_sq) {                                        // (uniform over the workgroup)
+            for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+            if ((lane & 31) == 0) sqr[wave][lane >> 5] = sq;
+            __syncthreads();
+            if (threadIdx.x < 2) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < 16; w++) a += sqr[w][threadIdx.x];
+                const int groups = (g.N + 31) >> 5;
+                if (NSUB == 4) {
+                    const int gi = 2 * tn + (int)threadIdx.x;
+                    if (gi < groups) g.sumsq[tm * groups + gi] = a;
+                } else {                                      // 32-column tile: one group, both halves of the wavefronts belong to it
+                    a += __shfl_xor(a, 1);
+                    if (threadIdx.x == 0) g.sumsq[tm * groups + tn] = a;
+                }
+            }
+            if (h == 0 && dual) __syncthreads();              // (the second tile's sums reuse sqr)
         }
     }
 }
@@ -200,10 +228,17 @@ __global__ __launch_bounds__(256) void sum_squares_kernel(const float* __restric
 // ... and every workgroup of the optimiser kernel adds the kNormBlocks partials up again (1 KB from L2).
 // torch.nn.utils.clip_grad_norm_(max_norm) followed by torch.optim.Adam.step() (no weight decay, no amsgrad) over flat buffers
 __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2,
-                                                      int64_t n, float* __restrict__ scalars, const float* __restrict__ partial, float max_norm,
-                                                      float beta1, float beta2, float eps) {
+                                                      int64_t n, float* __restrict__ scalars, const float* __restrict__ partial, int n_partials,
+                                                      float max_norm, float beta1, float beta2, float eps) {
     __shared__ float sw[4];
-    float s = partial[threadIdx.x];                            // blockDim.x == kNormBlocks
+    float s = 0.f;                                             // blockDim.x == 256
+    for (int i0 = threadIdx.x; i0 < n_partials; i0 += 8 * 256) {   // eight loads in flight (a plain loop waits for each in turn: +2 us)
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = i0 + 256 * u; t[u] = partial[i < n_partials ? i : i0]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += (i0 + 256 * u < n_partials) ? t[u] : 0.f;
+    }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -254,7 +289,7 @@ static bool gemm_ok(const UavGemm* g) {
     if (!g->A || !g->B || !g->C || g->M < 1 || g->N < 1 || g->K < 1 || g->ldc < g->N) return false;
     if ((g->a_sm != 1 && g->a_sk != 1) || (g->b_sk != 1 && g->b_sn != 1)) return false;
     return !(((g->flags & UAVENV_GEMM_BIAS) && !g->bias) || ((g->flags & UAVENV_GEMM_A_MASK) && !g->a_mask) ||
-             ((g->flags & UAVENV_GEMM_ROWSUM) && !g->row_sum));
+             ((g->flags & UAVENV_GEMM_ROWSUM) && !g->row_sum) || ((g->flags & UAVENV_GEMM_SUMSQ) && !g->sumsq));
 }
 extern "C" int uavenv_gemm_f32(const UavGemm* first, const UavGemm* second, void* stream) {
     if (!first || !gemm_ok(first) || (second && !gemm_ok(second))) return UAVENV_E_INVALID;
@@ -295,16 +330,22 @@ extern "C" int uavenv_td_loss(const float* q_dev, const float* q_next_dev, const
 }
 
 // replaces: clip_grad_norm_(parameters, max_norm) + Adam.step() of SB3's DQN.train over ONE flat buffer of n parameters
-// (the caller keeps the module's parameters as views of it): two launches -- sums of squares per workgroup into workspace_dev
-// (float [UAVENV_UPD_WORKSPACE]), then clip + Adam with the learning rate scalars[UAVENV_UPD_LR] and the bias corrections
-// uavenv_td_loss wrote; scalars[UAVENV_UPD_NORM2] receives the squared gradient norm.
+// (the caller keeps the module's parameters as views of it): clip + Adam with the learning rate scalars[UAVENV_UPD_LR] and the bias
+// corrections uavenv_td_loss wrote, on the n_partials partial sums of squares the weight-gradient products left in workspace_dev
+// (UAVENV_GEMM_SUMSQ); n_partials == 0: a launch of its own computes them first (float [UAVENV_UPD_WORKSPACE]) -- what a caller
+// that changed the gradients after the products (an all-reduce over ranks) needs.  scalars[UAVENV_UPD_NORM2] receives the squared norm.
 extern "C" int uavenv_clip_adam(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n,
-                                float* scalars_dev, float* workspace_dev, float max_norm, float beta1, float beta2, float eps, void* stream) {
-    if (!param_dev || !grad_dev || !exp_avg_dev || !exp_avg_sq_dev || !scalars_dev || !workspace_dev || n < 1) return UAVENV_E_INVALID;
-    sum_squares_kernel<<<dim3(kNormBlocks), dim3(256), 0, (hipStream_t)stream>>>(grad_dev, n, workspace_dev);
+                                float* scalars_dev, float* workspace_dev, int32_t n_partials, float max_norm, float beta1, float beta2,
+                                float eps, void* stream) {
+    if (!param_dev || !grad_dev || !exp_avg_dev || !exp_avg_sq_dev || !scalars_dev || !workspace_dev || n < 1 || n_partials < 0)
+        return UAVENV_E_INVALID;
+    if (n_partials == 0) {
+        sum_squares_kernel<<<dim3(kNormBlocks), dim3(256), 0, (hipStream_t)stream>>>(grad_dev, n, workspace_dev);
+        n_partials = kNormBlocks;
+    }
     const unsigned blocks = (unsigned)((n + 256 * 4 - 1) / (256 * 4) < 2048 ? (n + 256 * 4 - 1) / (256 * 4) : 2048);
-    clip_adam_kernel<<<dim3(blocks), dim3(kNormBlocks), 0, (hipStream_t)stream>>>(param_dev, grad_dev, exp_avg_dev, exp_avg_sq_dev, n, scalars_dev,
-                                                                               workspace_dev, max_norm, beta1, beta2, eps);
+    clip_adam_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(param_dev, grad_dev, exp_avg_dev, exp_avg_sq_dev, n, scalars_dev,
+                                                                       workspace_dev, n_partials, max_norm, beta1, beta2, eps);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_E_HIP;
 }
 

@@ -417,7 +417,7 @@ class DQNLearner:
     def _apply(self):
         """clip_grad_norm_ + Adam on the (averaged) gradients."""
         if self._mlp is not None:
-            self._mlp.apply()
+            self._mlp.apply(grads_changed=self.world > 1)       # (several ranks: the partial sums of the norm predate the all-reduce)
             return
         if self.world > 1:
             self._unflatten_grads()

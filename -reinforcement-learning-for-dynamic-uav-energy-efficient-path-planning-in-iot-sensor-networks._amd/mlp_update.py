@@ -1,4 +1,4 @@
-"""One DQN gradient step of the reference's MLP policy as 12 HIP launches (csrc/uavenv_learner.hip) instead of ~60 PyTorch
+"""One DQN gradient step of the reference's MLP policy as 11 HIP launches (csrc/uavenv_learner.hip) instead of ~60 PyTorch
 ones: what stable-baselines3's `DQN.train()` does per gradient step for `MlpPolicy` with `net_arch=[512, 512, 256]`
 (agents/dqn/dqn.py:1077-1099) -- forward of the online and the target network, smooth-L1 TD loss, backward, clip_grad_norm_,
 Adam -- on one sampled batch.  torch is plumbing here (device buffers, the modules whose parameters become views of one flat
@@ -58,7 +58,12 @@ class FusedMLPUpdate:
         # addresses, and the parameter count of the reference network is odd)
         act0 = -(-self.n_params // 64) * 64
         self.work = torch.zeros(act0 + 2 * act + self.B * sum(outs[:-1]) + self.B * outs[-1], **f32)
-        self.norm_workspace = torch.zeros(N.UPD_WORKSPACE, **f32)
+        # the gradient norm's partial sums: every weight-gradient product leaves its own (bias gradient included)
+        shapes = [(m.out_features, m.in_features) for m in self.layers]
+        self.sq_off = [0]
+        for M_, N_ in shapes:
+            self.sq_off.append(self.sq_off[-1] + N.gemm_sumsq_count(M_, N_))
+        self.norm_workspace = torch.zeros(max(N.UPD_WORKSPACE, self.sq_off[-1]), **f32)
         z = self.work
         self.grad = z[:self.n_params]
         off = 0
@@ -88,10 +93,10 @@ class FusedMLPUpdate:
 
     # ---- helpers -----------------------------------------------------------------------------------------------
     @staticmethod
-    def _product(A, Bm, Cm, M, Nn, K, a_sm, a_sk, b_sk, b_sn, flags=0, bias=None, mask=None, row_sum=None):
+    def _product(A, Bm, Cm, M, Nn, K, a_sm, a_sk, b_sk, b_sn, flags=0, bias=None, mask=None, row_sum=None, sumsq=None):
         dp = lambda t: None if t is None else t.data_ptr()
         return N.UavGemm(A=dp(A), B=dp(Bm), C=dp(Cm), bias=dp(bias), a_mask=dp(mask), row_sum=dp(row_sum), M=M, N=Nn, K=K, flags=flags,
-                         a_sm=a_sm, a_sk=a_sk, b_sk=b_sk, b_sn=b_sn, ldc=Cm.stride(0))
+                         a_sm=a_sm, a_sk=a_sk, b_sk=b_sk, b_sn=b_sn, ldc=Cm.stride(0), sumsq=dp(sumsq))
 
     def _launch(self, first, second, stream):
         rc = self.L.uavenv_gemm_f32(C.byref(first), None if second is None else C.byref(second), stream)
@@ -124,7 +129,8 @@ class FusedMLPUpdate:
     # ---- the update ----------------------------------------------------------------------------------------------
     def backward(self, batch):
         """sample -> loss -> gradients (in `self.grad`).  batch: dict of the ring's sample_stacked (obs, next_obs, action,
-        reward, valid).  Everything is enqueued on the current stream; nothing synchronises.  9 launches: a layer of the online
+        reward, valid).  Everything is enqueued on the current stream; nothing synchronises.  9 launches (the weight-gradient
+        products also leave the gradient norm's partial sums): a layer of the online
         and of the target network share one, so do a layer's weight gradient and the gradient w.r.t. its input."""
         B = self.B
         obs, nxt = batch["obs"], batch["next_obs"]
@@ -148,7 +154,8 @@ class FusedMLPUpdate:
             mflag = N.GEMM_A_MASK if mask is not None else 0
             # dW[n][k] = sum_b dz[b][n] act(x[b][k]);  db[n] = sum_b dz[b][n]   (A = dz read transposed, B = x; the sum runs over b)
             dw = self._product(dz, x_in, self.gw[l], n, K, B, 1, dz.stride(0), x_in.stride(0), 1,
-                               flags=mflag | N.GEMM_ROWSUM | (N.GEMM_B_RELU if l > 0 else 0), mask=mask, row_sum=self.gb[l])
+                               flags=mflag | N.GEMM_ROWSUM | N.GEMM_SUMSQ | (N.GEMM_B_RELU if l > 0 else 0), mask=mask, row_sum=self.gb[l],
+                               sumsq=self.norm_workspace[self.sq_off[l]:])
             dx = None
             if l > 0:
                 # da[b][k] = sum_n dz[b][n] W[n][k]
@@ -157,12 +164,14 @@ class FusedMLPUpdate:
             if l > 0:
                 dz, mask = self.da[l - 1], self.z[l - 1]
 
-    def apply(self):
-        """clip_grad_norm_ + Adam over the flat buffers, with the gradients as they stand in `self.grad` (several ranks: after
-        their all-reduce)."""
+    def apply(self, grads_changed=False):
+        """clip_grad_norm_ + Adam over the flat buffers, with the gradients as they stand in `self.grad`.  The squared norm comes
+        from the partial sums `backward` left -- unless `grads_changed` (several ranks: `self.grad` has been all-reduced since):
+        then one more launch recomputes it from `self.grad`."""
         stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
         rc = self.L.uavenv_clip_adam(_p(self.flat), _p(self.grad), _p(self.exp_avg), _p(self.exp_avg_sq), self.n_params, _p(self.scalars),
-                                     _p(self.norm_workspace), self.max_norm, self.beta1, self.beta2, self.eps, stream)
+                                     _p(self.norm_workspace), 0 if grads_changed else self.sq_off[-1], self.max_norm, self.beta1,
+                                     self.beta2, self.eps, stream)
         if rc:
             raise RuntimeError(f"uavenv_clip_adam failed ({rc})")
 

@@ -340,6 +340,10 @@ int uavenv_attention_features(const float* obs_dev, const float* weights_dev, fl
 #define UAVENV_GEMM_B_RELU   4   /* B is used as max(B, 0)                                                                        */
 #define UAVENV_GEMM_BIAS     8   /* bias[n] is added to every row (once)                                                          */
 #define UAVENV_GEMM_ROWSUM  16   /* row_sum[m] += sum_k A(m, k) after the transform: the bias gradient of a weight-gradient product */
+#define UAVENV_GEMM_SUMSQ   32   /* sumsq[..] receives sums of squares of everything the product wrote (C and row_sum): the gradient
+                                  * norm's partial sums, one per (16-row tile, 32-column group): float [UAVENV_GEMM_SUMSQ_COUNT(M, N)],
+                                  * every entry written exactly once                                                                */
+#define UAVENV_GEMM_SUMSQ_COUNT(M, N) ((((M) + 15) / 16) * (((N) + 31) / 32))
 /* scalars block of the update (float [UAVENV_UPD_COUNT]) */
 enum { UAVENV_UPD_LOSS = 0, UAVENV_UPD_NORM2, UAVENV_UPD_STEP, UAVENV_UPD_BC1, UAVENV_UPD_BC2, UAVENV_UPD_LR, UAVENV_UPD_COUNT = 8 };
 /* one product C[M x N] = A . B (+ bias): A(m, k) = A[m * a_sm + k * a_sk], B(k, n) = B[k * b_sk + n * b_sn] (one stride of each
@@ -351,6 +355,7 @@ typedef struct UavGemm {
     float* row_sum;           /* UAVENV_GEMM_ROWSUM: float [M]      */
     int32_t M, N, K, flags;
     int64_t a_sm, a_sk, b_sk, b_sn, ldc;
+    float* sumsq;             /* UAVENV_GEMM_SUMSQ  */
 } UavGemm;
 /* replaces: torch.nn.Linear's three matrix products (forward, input gradient, weight gradient) at DQN batch sizes, where the
  * library GEMMs fill 16 of 256 CUs: on the f32 MFMA, one workgroup per 16 x 64 (or 16 x 32) output tile with K split over its 16
@@ -365,10 +370,13 @@ int uavenv_td_loss(const float* q_dev, const float* q_next_dev, const int64_t* a
 /* replaces: torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step (SB3 DQN: max_grad_norm 10, Adam) over ONE flat buffer of
  * n parameters: the gradient is scaled by min(1, max_norm / (norm + 1e-6)) and Adam applied with the learning rate in
  * scalars[UAVENV_UPD_LR] and the bias corrections uavenv_td_loss left; scalars[UAVENV_UPD_NORM2] receives the squared norm.
- * workspace_dev: float [UAVENV_UPD_WORKSPACE]. */
+ * n_partials == 0: the norm is computed here (one more launch), workspace_dev: float [UAVENV_UPD_WORKSPACE] of scratch.
+ * n_partials > 0: workspace_dev holds that many partial sums of squares of the gradient already (the weight-gradient products
+ * left them: UAVENV_GEMM_SUMSQ) -- valid only while grad_dev is what those products wrote (not after an all-reduce). */
 #define UAVENV_UPD_WORKSPACE 256
 int uavenv_clip_adam(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n,
-                     float* scalars_dev, float* workspace_dev, float max_norm, float beta1, float beta2, float eps, void* stream);
+                     float* scalars_dev, float* workspace_dev, int32_t n_partials, float max_norm, float beta1, float beta2, float eps,
+                     void* stream);
 
 /* replaces: the action selection of SB3's DQN while collecting (argmax Q with probability 1 - epsilon, else a uniform action) for
  * a vector of environments, one launch instead of six: q_dev float [n_envs][n_actions], *eps_dev the exploration rate, *counter_dev

@@ -20,14 +20,14 @@ def _mods():
     return torch, U, N, LR, FusedMLPUpdate
 
 
-def _product(N, A, B, Cm, M, Nn, K, a_sm, a_sk, b_sk, b_sn, flags=0, bias=None, mask=None, row_sum=None):
+def _product(N, A, B, Cm, M, Nn, K, a_sm, a_sk, b_sk, b_sn, flags=0, bias=None, mask=None, row_sum=None, sumsq=None):
     dp = lambda t: None if t is None else t.data_ptr()
     return N.UavGemm(A=dp(A), B=dp(B), C=dp(Cm), bias=dp(bias), a_mask=dp(mask), row_sum=dp(row_sum), M=M, N=Nn, K=K, flags=flags,
-                     a_sm=a_sm, a_sk=a_sk, b_sk=b_sk, b_sn=b_sn, ldc=Cm.stride(0))
+                     a_sm=a_sm, a_sk=a_sk, b_sk=b_sk, b_sn=b_sn, ldc=Cm.stride(0), sumsq=dp(sumsq))
 
 
-def _gemm(torch, N, A, B, Cm, M, Nn, K, a_sm, a_sk, b_sk, b_sn, flags=0, bias=None, mask=None, row_sum=None, second=None):
-    g = _product(N, A, B, Cm, M, Nn, K, a_sm, a_sk, b_sk, b_sn, flags, bias, mask, row_sum)
+def _gemm(torch, N, A, B, Cm, M, Nn, K, a_sm, a_sk, b_sk, b_sn, flags=0, bias=None, mask=None, row_sum=None, second=None, sumsq=None):
+    g = _product(N, A, B, Cm, M, Nn, K, a_sm, a_sk, b_sk, b_sn, flags, bias, mask, row_sum, sumsq)
     rc = N.lib().uavenv_gemm_f32(C.byref(g), None if second is None else C.byref(second), C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0, rc
 
@@ -50,11 +50,23 @@ def test_small_batch_gemm_all_three_layouts_match_torch(M, Nn, K):
     want = (A * (Z > 0)).double() @ Bm.double()
     assert torch.allclose(Cm.double(), want, rtol=1e-4, atol=1e-4 * K ** 0.5)
     # weight-gradient layout: A(m, k) = S[k][m] (transposed read), B [K x N] contiguous along n with relu, row sums of A
+    # ... and the sums of squares of everything written, one per (16-row tile, 32-column group), every entry exactly once
     S, rs = r(K, M), torch.full((M,), 3.0, device="cuda")
-    _gemm(torch, N, S, Bm, Cm, M, Nn, K, 1, M, Nn, 1, flags=N.GEMM_B_RELU | N.GEMM_ROWSUM, row_sum=rs)
+    nsq = N.gemm_sumsq_count(M, Nn)
+    sq = torch.full((nsq + 3,), -1.0, device="cuda")
+    _gemm(torch, N, S, Bm, Cm, M, Nn, K, 1, M, Nn, 1, flags=N.GEMM_B_RELU | N.GEMM_ROWSUM | N.GEMM_SUMSQ, row_sum=rs, sumsq=sq)
     want = S.double().t() @ torch.relu(Bm).double()
     assert torch.allclose(Cm.double(), want, rtol=1e-4, atol=1e-4 * K ** 0.5)
     assert torch.allclose(rs.double(), S.double().sum(0), rtol=1e-4, atol=1e-4 * K ** 0.5)
+    assert bool((sq[nsq:] == -1).all()) and bool((sq[:nsq] >= 0).all())
+    groups = (Nn + 31) // 32
+    pad = torch.zeros(-(-M // 16) * 16, groups * 32, dtype=torch.float64, device="cuda")
+    pad[:M, :Nn] = Cm.double() ** 2
+    want_sq = pad.view(-1, 16, groups, 32).sum((1, 3))
+    rpad = torch.zeros(-(-M // 16) * 16, dtype=torch.float64, device="cuda")
+    rpad[:M] = rs.double() ** 2
+    want_sq[:, 0] += rpad.view(-1, 16).sum(1)                # the row sums (a bias gradient) count in their tile's first group
+    assert torch.allclose(sq[:nsq].double().view(-1, groups), want_sq, rtol=1e-4, atol=1e-6), float((sq[:nsq].double().view(-1, groups) - want_sq).abs().max())
     # a strided output (a sub-block of a wider matrix): nothing outside it is touched
     wide = torch.ones(M, Nn + 7, device="cuda")
     sub = wide[:, 3:3 + Nn]
@@ -126,7 +138,9 @@ def test_fused_update_matches_autograd_and_adam(arch, B):
             mine = [t for pair in zip(upd.gw, upd.gb) for t in pair]
             for a, b_ in zip(mine, gref):
                 assert torch.allclose(a, b_, rtol=1e-4, atol=1e-6), float((a - b_).abs().max())
-        upd.apply()
+        norm2 = float((upd.grad.double() ** 2).sum())
+        upd.apply(grads_changed=(it == 1))                   # (it 1: the norm recomputed from the flat gradients, as after an all-reduce)
+        assert float(upd.scalars[N.UPD_NORM2]) == pytest.approx(norm2, rel=1e-5)       # (else: from the products' partial sums)
         assert float(upd.loss) == pytest.approx(float(loss_ref.detach()), rel=1e-5)
         for a, b_ in zip(q.parameters(), q_ref.parameters()):
             diff = (a.detach() - b_.detach()).abs()
