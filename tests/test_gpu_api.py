@@ -403,14 +403,18 @@ def test_vec_env_with_builtin_frame_stack():
     a.close(); b.close()
 
 
-def test_hip_ring_gather_equals_the_pytorch_statement():
+@pytest.mark.parametrize("k,sensors,positions", [(5, 10, False), (1, 10, False), (4, 10, False), (12, 10, False), (16, 10, False),
+                                                 (4, 50, True), (3, 64, True)])
+def test_hip_ring_gather_equals_the_pytorch_statement(k, sensors, positions):
     """uavenv_ring_gather_stacked (one launch per sampled batch) against TransitionRing.stacked_batch_at_torch (the tensor
     expressions it replaces), on a chunked ring that has wrapped around, with a terminal section too small for the episode-end
-    bursts (overwritten rows must come back as valid = False) and draws that reach before the ring start."""
+    bursts (overwritten rows must come back as valid = False) and draws that reach before the ring start.  Stack depths on both
+    sides of the kernel's compile-time bounds (4, 10, 16); rows of 33, 253 and 323 floats (the last one takes two passes)."""
     torch, U, O = _mods()
-    E, k = 40, 5
-    env = U.BatchedUAVEnv(E, num_sensors=10, max_steps=7, seed=11)       # every environment ends an episode every 7 steps
+    E = 40
+    env = U.BatchedUAVEnv(E, num_sensors=sensors, max_steps=7, seed=11, include_sensor_positions=positions)   # an episode ends every 7 steps
     D = env.obs_dim
+    assert D == 3 + sensors * (5 if positions else 3)
     ring = U.TransitionRing(24, E, D, env.device, chunk_len=6, terminal_rows=16); ring.attach(env)
     obs = env.reset(); ring.local_obs_slot().copy_(obs)
     z = torch.zeros(E, device=env.device); ring.commit(z, z, z)
@@ -420,7 +424,7 @@ def test_hip_ring_gather_equals_the_pytorch_statement():
     g = torch.Generator(device=env.device).manual_seed(4)
     B = 3000
     j = torch.randint(0, n - 1, (B,), generator=g, device=env.device)
-    j[:40] = torch.arange(40, device=env.device) % 4                       # stacks that reach before the ring start
+    j[:40] = torch.arange(40, device=env.device) % max(1, min(4, k - 1))   # stacks that reach before the ring start
     slot = (oldest + j) % ring.capacity
     r = torch.zeros(B, dtype=torch.int64, device=env.device)
     e = torch.randint(0, E, (B,), generator=g, device=env.device)
@@ -430,7 +434,8 @@ def test_hip_ring_gather_equals_the_pytorch_statement():
         assert got[key].dtype == want[key].dtype and got[key].shape == want[key].shape, key
         assert torch.equal(got[key], want[key]), key
     assert bool(got["done"].any()) and not bool(got["valid"].all()) and bool(got["valid"].any())
-    assert bool((got["obs"][:40, :D] == 0).all())                          # the frames from before the ring start are zero
+    if k > 4:
+        assert bool((got["obs"][:40, :D] == 0).all())                      # the frames from before the ring start are zero
     env.close()
 
 
