@@ -1595,17 +1595,28 @@ __global__ __launch_bounds__(kSmallBlockThreads) void uav_frame_stack_kernel(flo
                                                                       const float* terminal_obs, float* terminal_stacked,
                                                                       int32_t num_envs, int32_t k, int32_t D) {
     const int lane = threadIdx.x & 63;
-    const int env = blockIdx.x * (kSmallBlockThreads / 64) + (threadIdx.x >> 6);
+    const int env = __builtin_amdgcn_readfirstlane(blockIdx.x * (kSmallBlockThreads / 64) + (threadIdx.x >> 6));   // (wave-uniform, and the compiler knows)
     if (env >= num_envs) return;
     const int row = k * D, keep = row - D;
     float* s = stacked + (size_t)env * row;
-    const bool dn = done != nullptr && done[env] != 0;
+    const float* o = obs + (size_t)env * D;
+    // every load of the row -- the k-1 older frames, the new observation, the done flag -- is issued before the first wait: one
+    // trip to memory per environment (the flag first, then the frames, then the observation was three).  Slots past the row are
+    // skipped by a scalar branch; inside the row the address is selected, not the load predicated.
     float v[kFsMaxPerLane];
 #pragma unroll
     for (int j = 0; j < kFsMaxPerLane; j++) {
-        const int i = lane + 64 * j;
-        v[j] = (i < keep) ? s[i + D] : 0.0f;              // old frames 1..k-1 -> positions 0..k-2
+        v[j] = 0.0f;
+        if (64 * j < row) {
+            const int i = lane + 64 * j;
+            const float* src = (i < keep) ? s + i + D : o + ((i < row) ? i - keep : 0);     // old frames 1..k-1 -> positions 0..k-2 | obs
+            v[j] = *src;
+        }
     }
+    const uint8_t dflag = done != nullptr ? done[env] : (uint8_t)0;
+#pragma unroll
+    for (int j = 0; j < kFsMaxPerLane; j++) asm volatile("" : "+v"(v[j]));     // (keeps the loads above the flag's wait)
+    const bool dn = dflag != 0;
     if (dn && terminal_stacked != nullptr && terminal_obs != nullptr) {
         float* t = terminal_stacked + (size_t)env * row;
         const float* to = terminal_obs + (size_t)env * D;
@@ -1616,12 +1627,13 @@ __global__ __launch_bounds__(kSmallBlockThreads) void uav_frame_stack_kernel(flo
             else if (i < row) t[i] = to[i - keep];
         }
     }
-    const float* o = obs + (size_t)env * D;
 #pragma unroll
     for (int j = 0; j < kFsMaxPerLane; j++) {
-        const int i = lane + 64 * j;
-        if (i < keep) s[i] = dn ? 0.0f : v[j];
-        else if (i < row) s[i] = o[i - keep];
+        if (64 * j < row) {
+            const int i = lane + 64 * j;
+            if (i < keep) s[i] = dn ? 0.0f : v[j];
+            else if (i < row) s[i] = v[j];
+        }
     }
 }
 
