@@ -68,11 +68,37 @@ class FusedAttentionFeatures:
         self.n_stack, self.device = int(n_stack), torch.device(device)
         self.weights = pack_attention_weights(sd, self.n_stack, self.device)
         self.L = N.lib()
+        self._gather = None
+
+    def _build_gather(self, module):
+        """The packing as ONE gather: the block is a fixed permutation (plus zero padding) of the module's parameters, so it is
+        read off once by packing tensors that hold their own positions in a flat copy of the parameters (position + 1; the
+        padding's zeros then point at slot 0, which holds 0.0)."""
+        sd = module.state_dict()
+        keys = [name for key in _NAMES for name in _NAMES[key] if name in sd]
+        tensors = [dict(module.named_parameters())[k] for k in keys]
+        sizes = [t.numel() for t in tensors]
+        assert sum(sizes) + 1 < 2 ** 24                        # (positions travel through float32 exactly)
+        fake, off = {}, 1
+        for k, t in zip(keys, tensors):
+            fake[k] = torch.arange(off, off + t.numel(), dtype=torch.float32, device=self.device).view_as(t)
+            off += t.numel()
+        idx = pack_attention_weights(fake, self.n_stack, self.device).round().to(torch.int64)
+        flat = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self._gather = (tensors, flat, idx, id(module))
 
     def refresh(self, module_or_state_dict):
-        """Re-pack the (updated) parameters into the same weight block: ~25 small device copies, no host round trip."""
-        sd = module_or_state_dict.state_dict() if hasattr(module_or_state_dict, "state_dict") else module_or_state_dict
-        pack_attention_weights(sd, self.n_stack, self.device, out=self.weights)
+        """Re-pack the (updated) parameters into the same weight block (same address: graph replays see it).  From a module: two
+        launches -- the parameters concatenated into a flat buffer, one gather through the packing's index map -- where packing
+        piece by piece is ~25 small copies; from a state dict: piece by piece."""
+        if hasattr(module_or_state_dict, "named_parameters"):
+            if self._gather is None or self._gather[3] != id(module_or_state_dict):
+                self._build_gather(module_or_state_dict)
+            tensors, flat, idx, _ = self._gather
+            torch.cat([t.detach().reshape(-1) for t in tensors], out=flat[1:])
+            torch.index_select(flat, 0, idx, out=self.weights)
+            return
+        pack_attention_weights(module_or_state_dict, self.n_stack, self.device, out=self.weights)
 
     def __call__(self, obs):
         assert obs.is_cuda and obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[1] == self.n_stack * 153

@@ -48,3 +48,31 @@ def test_fused_attention_matches_torch_module(n_stack, n):
     frac_masked = ((x[:, -150:].view(E, 50, 3)[:, :, 2] < 1e-6).float().mean().item())
     assert 0.2 < frac_masked < 1.0               # the mask is really exercised
     env.close()
+
+
+@pytest.mark.parametrize("n_stack", [10, 4])
+def test_weight_refresh_through_the_index_map_equals_the_piecewise_packing(n_stack):
+    """FusedAttentionFeatures.refresh(module) -- the parameters concatenated + ONE gather through an index map built from the
+    packing itself -- gives the block pack_attention_weights builds piece by piece, bit for bit, after the parameters changed
+    in place (an optimiser step) and for another module."""
+    import torch
+    import uavenv_amd as U
+    from uavenv_amd.attention import pack_attention_weights
+    m = _module(n_stack)
+    fused = U.FusedAttentionFeatures(m, n_stack, "cuda")
+    addr = fused.weights.data_ptr()
+    for _ in range(2):
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(0.1 * torch.randn_like(p))
+        fused.refresh(m)
+        assert fused.weights.data_ptr() == addr                           # same block: captured launches keep reading it
+        assert torch.equal(fused.weights, pack_attention_weights(m.state_dict(), n_stack, "cuda"))
+    other = _module(n_stack)
+    with torch.no_grad():
+        for p in other.parameters():
+            p.mul_(1.5)
+    fused.refresh(other)                                                  # another module: the map is rebuilt for its tensors
+    assert torch.equal(fused.weights, pack_attention_weights(other.state_dict(), n_stack, "cuda"))
+    fused.refresh(m.state_dict())                                         # a state dict: the piecewise path
+    assert torch.equal(fused.weights, pack_attention_weights(m.state_dict(), n_stack, "cuda"))
