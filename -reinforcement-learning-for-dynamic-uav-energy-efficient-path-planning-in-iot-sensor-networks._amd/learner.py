@@ -189,13 +189,21 @@ class DQNLearner:
         # launches) instead of torch autograd + torch.optim.Adam (~60 launches, a dozen of them 256-row library GEMMs that use
         # 16 of 256 CUs); the modules' parameters become views of its flat buffers.  False keeps the PyTorch update (the attention
         # extractor always does: its backward is PyTorch's).
-        self.fused_update = (on_gpu and extractor == "mlp") if fused_update is None else bool(fused_update)
-        assert not (self.fused_update and extractor != "mlp"), "the fused update covers the MLP policy"
-        self._mlp = None
+        # With the attention extractor (one rank) the same kernels run the layers AFTER the extractor -- both networks' heads, the
+        # loss, the head's backward down to the gradient w.r.t. the features, clip + Adam of the head -- and autograd continues from
+        # that gradient through the extractor, whose parameters keep a torch Adam clipped by the same coefficient ("hybrid").
+        self.fused_update = (on_gpu and (extractor == "mlp" or (self.world == 1 and self.D == 153))) if fused_update is None else bool(fused_update)
+        assert not (self.fused_update and extractor != "mlp" and (self.world > 1 or self.D != 153 or not on_gpu)), \
+            "the hybrid update (attention extractor) is single-rank, on a GPU, for 153-float frames"
+        self._mlp, self._hybrid = None, False
         if self.fused_update:
             from .mlp_update import FusedMLPUpdate
+            self._hybrid = extractor != "mlp"
             self._mlp = FusedMLPUpdate(self.q, self.q_target, self.local_batch, self.gamma, self.max_grad_norm, self.reward_scale,
-                                       lr=self.lr_schedule(1.0))
+                                       lr=self.lr_schedule(1.0), input_grad=self._hybrid)
+            if self._hybrid:                                  # the head's parameters now belong to the library's optimiser
+                self.opt = torch.optim.Adam(self.q.features.parameters(), lr=torch.tensor(self.lr_schedule(1.0), device=self.dev),
+                                            capturable=True, fused=True)
         self.use_graphs = on_gpu if use_graphs is None else bool(use_graphs)
         self._act_graphs, self._train_graph, self._train_graph_b, self._fused = None, None, None, None
         # one flat buffer for the gradient all-reduce (world > 1)
@@ -303,7 +311,8 @@ class DQNLearner:
     def _set_lr(self, lr):
         if self._mlp is not None:
             self._mlp.set_lr(lr)
-            return
+            if not self._hybrid:
+                return
         for g in self.opt.param_groups:
             if torch.is_tensor(g["lr"]):
                 g["lr"].fill_(lr)
@@ -397,13 +406,39 @@ class DQNLearner:
             return self._keyed_out
         return self.ring.sample_stacked(self.local_batch, self.k, generator=self.gen, window=window)
 
+    def _target_features(self, x):
+        """The target network's extractor on a batch (no gradients): the fused inference kernel, from a weight block re-packed
+        here from the target network's parameters as they stand (2 launches; the hard target updates happen in three places, this
+        is the one place the block is read)."""
+        if self.__dict__.get("_fused_target") is None:
+            from .attention import FusedAttentionFeatures
+            self._fused_target = FusedAttentionFeatures(self.q_target.features, self.k, self.dev)
+        self._fused_target.refresh(self.q_target.features)
+        return self._fused_target(x)
+
+    def _target_q(self, x):
+        """Q-values of the target network (no gradients).  The attention extractor's forward runs in the fused inference kernel,
+        from a weight block re-packed here from the target network's parameters as they stand (2 launches; the hard target
+        updates happen in three places, this is the one place the block is read) -- ~15 eager launches less per update."""
+        if self.dev.type != "cuda" or not isinstance(self.q_target.features, AttentionFeatures) or self.D != 153:
+            return self.q_target(x)
+        return self.q_target.head(self._target_features(x))
+
     def _backward(self, batch):
         """Loss and gradients of one batch (several ranks: the gradients end up in the flat buffer the all-reduce works on).
         Returns the detached loss."""
+        if self._hybrid:
+            feat = self.q.features(batch["obs"])
+            with torch.no_grad():
+                feat_next = self._target_features(batch["next_obs"])
+            self._mlp.backward(dict(batch, obs=feat.detach(), next_obs=feat_next))
+            self.opt.zero_grad(set_to_none=True)
+            feat.backward(self._mlp.dx0)
+            return self._mlp.loss
         if self._mlp is not None:
             self._mlp.backward(batch)
             return self._mlp.loss
-        loss = td_loss(self.q, self.q_target, batch, self.gamma, self.reward_scale)
+        loss = td_loss(self.q, self._target_q, batch, self.gamma, self.reward_scale)
         # (one rank inside a capture: fresh gradient tensors from the graph's pool; several ranks: the tensors are part of both graphs)
         self.opt.zero_grad(set_to_none=self.world == 1)
         loss.backward()
@@ -416,6 +451,16 @@ class DQNLearner:
 
     def _apply(self):
         """clip_grad_norm_ + Adam on the (averaged) gradients."""
+        if self._hybrid:
+            # clip_grad_norm_ over ALL parameters: the extractor's share of the squared norm joins the head's partial sums, the
+            # library's kernel clips + steps the head and leaves the total, the extractor's gradients take the same coefficient
+            grads = [p.grad for p in self.q.features.parameters()]
+            self._mlp.apply(extra_norm2=torch.stack(torch._foreach_norm(grads)).square().sum())
+            torch._foreach_mul_(grads, self._mlp.clip_coefficient())
+            self.opt.step()
+            if self._fused is not None:
+                self._fused.refresh(self.q.features)
+            return
         if self._mlp is not None:
             self._mlp.apply(grads_changed=self.world > 1)       # (several ranks: the partial sums of the norm predate the all-reduce)
             return

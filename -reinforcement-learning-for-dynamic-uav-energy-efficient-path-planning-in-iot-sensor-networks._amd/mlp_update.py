@@ -27,9 +27,13 @@ class FusedMLPUpdate:
     re-pointed to views of `self.flat` / `self.flat_target` (same values), so `q(x)` for acting sees every update.
     """
 
-    def __init__(self, q, q_target, batch_size, gamma, max_grad_norm, reward_scale=1.0, betas=(0.9, 0.999), eps=1e-8, lr=1e-3):
+    def __init__(self, q, q_target, batch_size, gamma, max_grad_norm, reward_scale=1.0, betas=(0.9, 0.999), eps=1e-8, lr=1e-3,
+                 input_grad=False):
         self.L = N.lib()
         self.q, self.q_target = q, q_target
+        # input_grad: also produce `self.dx0`, the gradient w.r.t. the first layer's input -- a features extractor in front of
+        # the layers (the attention extractor) continues the backward pass from it with autograd
+        self.input_grad = bool(input_grad)
         self.layers = [m for m in q.head if isinstance(m, nn.Linear)]
         self.layers_t = [m for m in q_target.head if isinstance(m, nn.Linear)]
         assert len(self.layers) >= 1 and all(isinstance(m, (nn.Linear, nn.ReLU)) for m in q.head)
@@ -63,7 +67,7 @@ class FusedMLPUpdate:
         self.sq_off = [0]
         for M_, N_ in shapes:
             self.sq_off.append(self.sq_off[-1] + N.gemm_sumsq_count(M_, N_))
-        self.norm_workspace = torch.zeros(max(N.UPD_WORKSPACE, self.sq_off[-1]), **f32)
+        self.norm_workspace = torch.zeros(max(N.UPD_WORKSPACE, self.sq_off[-1] + 1), **f32)     # (+ 1: apply's extra_norm2)
         z = self.work
         self.grad = z[:self.n_params]
         off = 0
@@ -89,6 +93,7 @@ class FusedMLPUpdate:
         self.dq = z[cur:cur + self.B * outs[-1]].view(self.B, outs[-1]); cur += self.B * outs[-1]
         self.scalars = torch.zeros(N.UPD_COUNT, **f32)     # loss | norm^2 | step | bias corrections | lr   (step persists: not zeroed)
         self.K0, self.outs = K0, outs
+        self.dx0 = torch.zeros(self.B, K0, **f32) if self.input_grad else None
         self.scalars[N.UPD_LR] = float(lr)
 
     # ---- helpers -----------------------------------------------------------------------------------------------
@@ -157,23 +162,35 @@ class FusedMLPUpdate:
                                flags=mflag | N.GEMM_ROWSUM | N.GEMM_SUMSQ | (N.GEMM_B_RELU if l > 0 else 0), mask=mask, row_sum=self.gb[l],
                                sumsq=self.norm_workspace[self.sq_off[l]:])
             dx = None
-            if l > 0:
+            if l > 0 or self.input_grad:
                 # da[b][k] = sum_n dz[b][n] W[n][k]
-                dx = self._product(dz, self.w[l], self.da[l - 1], B, K, n, dz.stride(0), 1, self.w[l].stride(0), 1, flags=mflag, mask=mask)
+                dx = self._product(dz, self.w[l], self.da[l - 1] if l > 0 else self.dx0, B, K, n, dz.stride(0), 1, self.w[l].stride(0), 1,
+                                   flags=mflag, mask=mask)
             self._launch(dw, dx, stream)
             if l > 0:
                 dz, mask = self.da[l - 1], self.z[l - 1]
 
-    def apply(self, grads_changed=False):
+    def apply(self, grads_changed=False, extra_norm2=None):
         """clip_grad_norm_ + Adam over the flat buffers, with the gradients as they stand in `self.grad`.  The squared norm comes
         from the partial sums `backward` left -- unless `grads_changed` (several ranks: `self.grad` has been all-reduced since):
-        then one more launch recomputes it from `self.grad`."""
+        then one more launch recomputes it from `self.grad`.  extra_norm2 (a device scalar): the squared gradient norm of
+        parameters that are NOT in the flat buffer but are clipped together with it (a features extractor trained by autograd);
+        scalars[UPD_NORM2] is the total, from which the caller scales those gradients by the same coefficient."""
         stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        n_partials = 0 if grads_changed else self.sq_off[-1]
+        if extra_norm2 is not None:
+            assert not grads_changed
+            self.norm_workspace[n_partials:n_partials + 1].copy_(extra_norm2.reshape(1))
+            n_partials += 1
         rc = self.L.uavenv_clip_adam(_p(self.flat), _p(self.grad), _p(self.exp_avg), _p(self.exp_avg_sq), self.n_params, _p(self.scalars),
-                                     _p(self.norm_workspace), 0 if grads_changed else self.sq_off[-1], self.max_norm, self.beta1,
+                                     _p(self.norm_workspace), n_partials, self.max_norm, self.beta1,
                                      self.beta2, self.eps, stream)
         if rc:
             raise RuntimeError(f"uavenv_clip_adam failed ({rc})")
+
+    def clip_coefficient(self):
+        """min(1, max_norm / (norm + 1e-6)) of the last `apply` (torch.nn.utils.clip_grad_norm_'s factor), as a device scalar."""
+        return torch.clamp(self.max_norm / (self.scalars[N.UPD_NORM2].sqrt() + 1e-6), max=1.0)
 
     def update(self, batch):
         self.backward(batch)

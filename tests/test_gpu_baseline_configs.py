@@ -95,7 +95,9 @@ def test_config3_learner_4096x50_graph_path_equals_eager_and_oracle(extractor, n
         L.learn(total_timesteps=E * steps)
     torch.cuda.synchronize()
     assert Lg._act_graphs is not None and Lg._train_graph is not None and Le._act_graphs is None
-    assert (Lg._mlp is not None) == (extractor == "mlp")          # the MLP policy's update runs in the library's own kernels
+    # the layers after the extractor (all of the MLP policy) are updated by the library's own kernels; the attention extractor
+    # itself by autograd + torch Adam, clipped with the same coefficient
+    assert Lg._mlp is not None and Lg._hybrid == (extractor == "attention")
     # (a rollout is followed by an update once the ring holds n_stack + 2 slots: 9 of the 10 rollouts with 4 frames, 8 with 10)
     assert Lg.n_updates == Le.n_updates == (9 if n_stack == 4 else 8) and Lg.n_calls == Le.n_calls == steps
     rg, re_ = Lg.ring, Le.ring
@@ -130,11 +132,16 @@ def test_config3_learner_4096x50_graph_path_equals_eager_and_oracle(extractor, n
     # (1) the GRADIENTS of the captured update against the hand-made ones: the well-conditioned comparison, possible where the update
     #     keeps them in a buffer of its own (the library's update; the PyTorch update's gradient tensors live in the graph's pool and
     #     are recycled by later nodes of the same graph)
-    if Lg._mlp is not None:
-        got = [t for pair in zip(Lg._mlp.gw, Lg._mlp.gb) for t in pair]
-        gmax = max(float(w.abs().max()) for w in raw)
-        for (name, _), g_, w_ in zip(Lg.q.named_parameters(), got, raw):
-            assert float((g_ - w_).abs().max()) <= 2e-4 * max(float(w_.abs().max()), 1e-3 * gmax), (name, float((g_ - w_).abs().max()))
+    got = [t for pair in zip(Lg._mlp.gw, Lg._mlp.gb) for t in pair]
+    names = [n_ for n_, _ in Lg.q.named_parameters()]
+    raw_head = raw[len(raw) - len(got):]                         # (the head's parameters come last; the MLP policy is all head)
+    gmax = max(float(w.abs().max()) for w in raw)
+    for name, g_, w_ in zip(names[len(raw) - len(got):], got, raw_head):
+        assert float((g_ - w_).abs().max()) <= 2e-4 * max(float(w_.abs().max()), 1e-3 * gmax), (name, float((g_ - w_).abs().max()))
+    # (the total norm the clipping used: head + extractor)
+    want_norm2 = float(sum((w.double() ** 2).sum() for w in raw))
+    from uavenv_amd import _native as N
+    assert float(Lg._mlp.scalars[N.UPD_NORM2]) == pytest.approx(want_norm2, rel=2e-3)
     # (2) the PARAMETERS after Adam: its step is lr * m / (sqrt(v) + 1e-8), and where gradients are cancellation noise (the attention's
     #     in-projection biases: 1e-7 out of summands of 1e-3; the key bias is exactly zero in theory) last-bit differences between graph
     #     replay and eager launches become visible fractions of lr.  Every element must stay within a step; the well-conditioned
