@@ -187,8 +187,7 @@ class DQNLearner:
         # fused_update (default: on for the MLP policy on a GPU): the gradient step runs in the library's own kernels
         # (mlp_update.py / csrc/uavenv_learner.hip: small-batch MFMA GEMMs, TD loss, clip + Adam over one flat buffer, ~20
         # launches) instead of torch autograd + torch.optim.Adam (~60 launches, a dozen of them 256-row library GEMMs that use
-        # 16 of 256 CUs); the modules' parameters become views of its flat buffers.  False keeps the PyTorch update (the attention
-        # extractor always does: its backward is PyTorch's).
+        # 16 of 256 CUs); the modules' parameters become views of its flat buffers.  False keeps the PyTorch update.
         # With the attention extractor (one rank) the same kernels run the layers AFTER the extractor -- both networks' heads, the
         # loss, the head's backward down to the gradient w.r.t. the features, clip + Adam of the head -- and autograd continues from
         # that gradient through the extractor, whose parameters keep a torch Adam clipped by the same coefficient ("hybrid").
