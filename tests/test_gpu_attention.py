@@ -76,3 +76,39 @@ def test_weight_refresh_through_the_index_map_equals_the_piecewise_packing(n_sta
     assert torch.equal(fused.weights, pack_attention_weights(other.state_dict(), n_stack, "cuda"))
     fused.refresh(m.state_dict())                                         # a state dict: the piecewise path
     assert torch.equal(fused.weights, pack_attention_weights(m.state_dict(), n_stack, "cuda"))
+
+
+@pytest.mark.parametrize("n_stack", [10, 4])
+def test_folded_training_forward_equals_the_module_form_values_and_gradients(n_stack):
+    """AttentionFeatures.forward (key projection folded into the query, value projection after the weighted mean, batched sensor
+    projection) against forward_module (nn.Linear + nn.MultiheadAttention, the reference's form) on real observations: features and
+    the gradients of every parameter under the same upstream gradient.  (in_proj_bias: the key bias' gradient is zero in theory and
+    cancellation noise in the module form -- compared on the query and value thirds.)"""
+    import torch
+    import uavenv_amd as U
+    E = 256
+    env = U.BatchedUAVEnv(E, num_sensors=20, pad_sensors=50, grid_size=(300, 300), seed=2, duty_cycle=50.0)
+    fs = U.FrameStack(E, env.obs_dim, n_stack, env.device)
+    stacked = fs.reset(env.reset())
+    for _ in range(n_stack + 2):
+        o, r, d = env.step_random()
+        stacked = fs.step(o, d, None)
+    x = stacked.clone()
+    x[0] = 0.0                                   # all tokens masked -> the unmask-everything branch
+    m = _module(n_stack).train()
+    up = torch.randn(E, 128, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    outs, grads = [], []
+    for f in (m.forward, m.forward_module):
+        m.zero_grad(set_to_none=True)
+        y = f(x)
+        (y * up).sum().backward()
+        outs.append(y.detach().clone())
+        grads.append({n: p.grad.detach().clone() for n, p in m.named_parameters()})
+    assert torch.allclose(outs[0], outs[1], rtol=1e-4, atol=2e-5), float((outs[0] - outs[1]).abs().max())
+    for name in grads[0]:
+        a, b = grads[0][name], grads[1][name]
+        if name == "attn.in_proj_bias":
+            a, b = torch.cat([a[:64], a[128:]]), torch.cat([b[:64], b[128:]])
+        scale = max(float(b.abs().max()), 1e-6)
+        assert float((a - b).abs().max()) <= 2e-4 * scale + 1e-6, (name, float((a - b).abs().max()), scale)
+    env.close()
