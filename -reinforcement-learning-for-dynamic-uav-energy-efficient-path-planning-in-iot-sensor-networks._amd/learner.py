@@ -218,7 +218,7 @@ class DQNLearner:
         # 16 of 256 CUs); the modules' parameters become views of its flat buffers.  False keeps the PyTorch update.
         # With the attention extractor (one rank) the same kernels run the layers AFTER the extractor -- both networks' heads, the
         # loss, the head's backward down to the gradient w.r.t. the features, clip + Adam of the head -- and autograd continues from
-        # that gradient through the extractor, whose parameters keep a torch Adam clipped by the same coefficient ("hybrid").
+        # that gradient through the extractor, into gradient views of the library's flat buffer: one clip + Adam launch for all ("hybrid").
         self.fused_update = (on_gpu and (extractor == "mlp" or (self.world == 1 and self.D == 153))) if fused_update is None else bool(fused_update)
         assert not (self.fused_update and extractor != "mlp" and (self.world > 1 or self.D != 153 or not on_gpu)), \
             "the hybrid update (attention extractor) is single-rank, on a GPU, for 153-float frames"
@@ -227,10 +227,9 @@ class DQNLearner:
             from .mlp_update import FusedMLPUpdate
             self._hybrid = extractor != "mlp"
             self._mlp = FusedMLPUpdate(self.q, self.q_target, self.local_batch, self.gamma, self.max_grad_norm, self.reward_scale,
-                                       lr=self.lr_schedule(1.0), input_grad=self._hybrid)
-            if self._hybrid:                                  # the head's parameters now belong to the library's optimiser
-                self.opt = torch.optim.Adam(self.q.features.parameters(), lr=torch.tensor(self.lr_schedule(1.0), device=self.dev),
-                                            capturable=True, fused=True)
+                                       lr=self.lr_schedule(1.0), input_grad=self._hybrid,
+                                       extra_params=list(self.q.features.parameters()) if self._hybrid else ())
+            self.opt = None                                   # (every parameter now belongs to the library's optimiser)
         self.use_graphs = on_gpu if use_graphs is None else bool(use_graphs)
         self._act_graphs, self._train_graph, self._train_graph_b, self._fused = None, None, None, None
         # one flat buffer for the gradient all-reduce (world > 1)
@@ -338,8 +337,7 @@ class DQNLearner:
     def _set_lr(self, lr):
         if self._mlp is not None:
             self._mlp.set_lr(lr)
-            if not self._hybrid:
-                return
+            return
         for g in self.opt.param_groups:
             if torch.is_tensor(g["lr"]):
                 g["lr"].fill_(lr)
@@ -459,8 +457,8 @@ class DQNLearner:
             with torch.no_grad():
                 feat_next = self._target_features(batch["next_obs"])
             self._mlp.backward(dict(batch, obs=feat.detach(), next_obs=feat_next))
-            self.opt.zero_grad(set_to_none=True)
-            feat.backward(self._mlp.dx0)
+            self._mlp.zero_extra_grads()
+            feat.backward(self._mlp.dx0)                       # (accumulates into views of the library's flat gradient buffer)
             return self._mlp.loss
         if self._mlp is not None:
             self._mlp.backward(batch)
@@ -479,12 +477,9 @@ class DQNLearner:
     def _apply(self):
         """clip_grad_norm_ + Adam on the (averaged) gradients."""
         if self._hybrid:
-            # clip_grad_norm_ over ALL parameters: the extractor's share of the squared norm joins the head's partial sums, the
-            # library's kernel clips + steps the head and leaves the total, the extractor's gradients take the same coefficient
-            grads = [p.grad for p in self.q.features.parameters()]
-            self._mlp.apply(extra_norm2=torch.stack(torch._foreach_norm(grads)).square().sum())
-            torch._foreach_mul_(grads, self._mlp.clip_coefficient())
-            self.opt.step()
+            # clip_grad_norm_ + Adam over ALL parameters in one launch: the extractor's parameters, gradients and moments live in the
+            # same flat buffers as the head's; its share of the squared norm joins the head's partial sums
+            self._mlp.apply()
             if self._fused is not None:
                 self._fused.refresh(self.q.features)
             return

@@ -28,12 +28,16 @@ class FusedMLPUpdate:
     """
 
     def __init__(self, q, q_target, batch_size, gamma, max_grad_norm, reward_scale=1.0, betas=(0.9, 0.999), eps=1e-8, lr=1e-3,
-                 input_grad=False):
+                 input_grad=False, extra_params=()):
         self.L = N.lib()
         self.q, self.q_target = q, q_target
         # input_grad: also produce `self.dx0`, the gradient w.r.t. the first layer's input -- a features extractor in front of
         # the layers (the attention extractor) continues the backward pass from it with autograd
         self.input_grad = bool(input_grad)
+        # extra_params: parameters OUTSIDE the layers (that extractor's) which this object optimises too -- they become views of
+        # the same flat buffers, their `.grad` views of the flat gradient buffer that autograd accumulates into (zeroed by
+        # `zero_extra_grads`), so that ONE clip + Adam launch covers the whole network
+        self.extra = list(extra_params)
         self.layers = [m for m in q.head if isinstance(m, nn.Linear)]
         self.layers_t = [m for m in q_target.head if isinstance(m, nn.Linear)]
         assert len(self.layers) >= 1 and all(isinstance(m, (nn.Linear, nn.ReLU)) for m in q.head)
@@ -47,10 +51,11 @@ class FusedMLPUpdate:
         sizes = []
         for m in self.layers:
             sizes += [m.weight.numel(), m.bias.numel()]
-        self.n_params = sum(sizes)
+        self.n_head = sum(sizes)
+        self.n_params = self.n_head + sum(p.numel() for p in self.extra)
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.flat = torch.empty(self.n_params, **f32)
-        self.flat_target = torch.empty(self.n_params, **f32)
+        self.flat_target = torch.empty(self.n_head, **f32)
         self.exp_avg = torch.zeros(self.n_params, **f32)
         self.exp_avg_sq = torch.zeros(self.n_params, **f32)
         self.w, self.b, self.wt, self.bt, self.gw, self.gb = [], [], [], [], [], []
@@ -83,6 +88,13 @@ class FusedMLPUpdate:
                 (self.wt if name == "weight" else self.bt).append(pt.data)
                 (self.gw if name == "weight" else self.gb).append(self.grad[off:off + n].view_as(p))
                 off += n
+        self.extra_grad = self.grad[off:]
+        for p in self.extra:
+            n = p.numel()
+            self.flat[off:off + n].copy_(p.detach().reshape(-1))
+            p.data = self.flat[off:off + n].view_as(p)
+            p.grad = self.grad[off:off + n].view_as(p)
+            off += n
         cur = act0
         self.z, self.zt, self.da = [], [], []
         for lst in (self.z, self.zt):                      # pre-activations of the online / the target network
@@ -112,8 +124,12 @@ class FusedMLPUpdate:
         self.scalars[N.UPD_LR] = float(lr)
 
     def sync_target(self):
-        """SB3's hard target update (tau = 1)."""
-        self.flat_target.copy_(self.flat)
+        """SB3's hard target update (tau = 1) of the layers."""
+        self.flat_target.copy_(self.flat[:self.n_head])
+
+    def zero_extra_grads(self):
+        """Before autograd accumulates the extra parameters' gradients (their `.grad` are views of the flat gradient buffer)."""
+        self.extra_grad.zero_()
 
     @property
     def loss(self):
@@ -178,6 +194,9 @@ class FusedMLPUpdate:
         scalars[UPD_NORM2] is the total, from which the caller scales those gradients by the same coefficient."""
         stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
         n_partials = 0 if grads_changed else self.sq_off[-1]
+        if self.extra and not grads_changed:                  # the extra parameters' share of the squared norm: one more partial sum
+            assert extra_norm2 is None
+            extra_norm2 = torch.dot(self.extra_grad, self.extra_grad)
         if extra_norm2 is not None:
             assert not grads_changed
             self.norm_workspace[n_partials:n_partials + 1].copy_(extra_norm2.reshape(1))

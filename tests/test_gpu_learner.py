@@ -29,19 +29,16 @@ def _torch_adam_twin(torch, L, q0):
     if L._mlp is None:
         opt0.load_state_dict(copy.deepcopy(L.opt.state_dict()))
         return opt0
-    # the library's flat moment buffers cover the layers after the extractor (all of the MLP policy); with the attention extractor
-    # ("hybrid") the extractor's moments are in the learner's torch Adam
+    # the library's flat buffers hold the layers after the extractor first, then ("hybrid") the extractor's parameters
     step = float(L._mlp.step_count)
-    if L._hybrid:
-        src = L.opt.state_dict()["state"]
-        for i, p in enumerate(q0.features.parameters()):
-            opt0.state[p] = {"step": src[i]["step"].clone().to(L.dev), "exp_avg": src[i]["exp_avg"].clone(), "exp_avg_sq": src[i]["exp_avg_sq"].clone()}
+    order = (list(q0.head.parameters()) + list(q0.features.parameters())) if L._hybrid else list(q0.parameters())
     off = 0
-    for p in (q0.head.parameters() if L._hybrid else q0.parameters()):
+    for p in order:
         n = p.numel()
         opt0.state[p] = {"step": torch.tensor(step, device=L.dev), "exp_avg": L._mlp.exp_avg[off:off + n].view_as(p).clone(),
                          "exp_avg_sq": L._mlp.exp_avg_sq[off:off + n].view_as(p).clone()}
         off += n
+    assert off == L._mlp.n_params
     return opt0
 
 
