@@ -11,7 +11,7 @@ stage = int(sys.argv[1])
 env = U.BatchedUAVEnv(96, num_sensors=10, max_steps=9, grid_size=(60, 60), seed=5)
 L = LR.DQNLearner(env, learning_rate=1e-2, buffer_size=96 * 40, batch_size=64, gamma=0.9, learning_starts=0,
                   target_update_interval=96 * 7, train_freq=2, gradient_steps=1, net_arch=(32, 16), n_stack=3,
-                  total_timesteps=10**6, max_grad_norm=0.5, seed=3, reward_scale=1e-3, use_graphs=False)
+                  total_timesteps=10**6, max_grad_norm=0.5, seed=3, reward_scale=1e-3, use_graphs=False, fused_update=False)   # (bisects the PyTorch update)
 L.collect(20)
 for _ in range(4): L.train(1)
 torch.cuda.synchronize()
