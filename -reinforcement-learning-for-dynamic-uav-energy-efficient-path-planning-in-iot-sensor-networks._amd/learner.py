@@ -279,6 +279,7 @@ class DQNLearner:
         self.ring.attach(env)
         self.fs = frame_stack_cls(self.E, self.D, self.k, self.dev)
         self.num_timesteps, self.n_calls, self.n_updates = 0, 0, 0
+        self._warm_act, self._warm_upd = 0, 0                       # eager vector steps / updates made by THIS object (graph capture waits for 3)
         self.last_loss = None
         self._stacked = None
 
@@ -303,7 +304,8 @@ class DQNLearner:
         import ctypes as C
         if self.__dict__.get("_act_out") is None:
             self._act_out = torch.zeros(self.E, dtype=torch.int32, device=self.dev)
-            self._act_counter = torch.zeros(1, dtype=torch.float32, device=self.dev)
+            if self.__dict__.get("_act_counter") is None:      # (a checkpoint may have put it there already)
+                self._act_counter = torch.zeros(1, dtype=torch.float32, device=self.dev)
             self._alib = N.lib()
         q = qvalues.contiguous()
         rc = self._alib.uavenv_epsilon_greedy(C.c_void_p(q.data_ptr()), self.E, q.shape[1], C.c_void_p(eps_dev.data_ptr()),
@@ -549,7 +551,7 @@ class DQNLearner:
         for _ in range(vector_steps):
             if self._act_graphs is not None and self._act_epoch != self.env.launch_epoch:
                 self._act_graphs = None          # env.seed() etc. since the capture: the launches carry stale arguments
-            if self._act_graphs is None and self.n_calls >= 3 and self._graphs_usable():  # (libraries are warm after 3 eager steps)
+            if self._act_graphs is None and self._warm_act >= 3 and self._graphs_usable():  # (libraries are warm after 3 eager steps OF THIS PROCESS: a loaded checkpoint brings its counters)
                 self._capture_act_graphs()
             if self._act_graphs is not None:
                 self._g_eps.fill_(self.exploration_rate())
@@ -566,6 +568,7 @@ class DQNLearner:
             self._stacked = self.fs.step(o, d, None)               # terminal rows live in the ring, not in env.terminal_obs
             self.num_timesteps += self.n_envs_total
             self.n_calls += 1
+            self._warm_act += 1
             if self.n_calls % self.target_every == 0:
                 self.q_target.load_state_dict(self.q.state_dict())
 
@@ -573,7 +576,7 @@ class DQNLearner:
     def train(self, gradient_steps=None):
         self._set_lr(self.lr_schedule(self.progress_remaining()))
         steps = self.gradient_steps if gradient_steps is None else gradient_steps
-        if self._graphs_usable() and self._train_graph is None and self.n_updates >= 3:
+        if self._graphs_usable() and self._train_graph is None and self._warm_upd >= 3:
             self._capture_train_graph()
         if self._train_graph is not None:
             self.ring.drain()                              # the gathers of finished chunks (host side; no-op alone)
@@ -595,6 +598,7 @@ class DQNLearner:
                 self._allreduce_grads()
             self._apply()
             self.n_updates += 1
+            self._warm_upd += 1
         self.last_loss = loss
         return self.last_loss
 
@@ -609,6 +613,79 @@ class DQNLearner:
                 self.train()
             if callback is not None and callback(self) is False:
                 break
+        return self
+
+    # ---- checkpoints ----------------------------------------------------------------------------------
+    def _moments(self):
+        """name -> (exp_avg, exp_avg_sq) views and the optimiser's step count, whichever optimiser holds them."""
+        named = dict(self.q.named_parameters())
+        if self._mlp is not None:
+            head = [(f"head.{n}", p) for n, p in self.q.head.named_parameters()]
+            extra = [(f"features.{n}", p) for n, p in self.q.features.named_parameters()] if self._hybrid else []
+            out, off = {}, 0
+            for name, p in head + extra:
+                n = p.numel()
+                out[name] = (self._mlp.exp_avg[off:off + n].view_as(p), self._mlp.exp_avg_sq[off:off + n].view_as(p))
+                off += n
+            assert off == self._mlp.n_params and set(out) == set(named)
+            return out, float(self._mlp.scalars[N.UPD_STEP])
+        out, step = {}, 0.0
+        for name, p in named.items():
+            st = self.opt.state.get(p)
+            if st:
+                out[name] = (st["exp_avg"], st["exp_avg_sq"])
+                step = float(st["step"])
+        return out, step
+
+    def save(self, path):
+        """What the reference's `model.save(...)` keeps of a DQN (dqn.py:1181, :1339: policy + optimiser + counters), as ONE
+        file of plain tensors and numbers (`torch.load(..., weights_only=True)` reads it): both networks, Adam's moments and
+        step, the time-step / update counters the schedules run on, the sampling generator.  Not the replay ring (SB3 keeps that
+        apart too, `save_replay_buffer`): a resumed learner collects `n_stack + 2` vector steps before its first update."""
+        moments, step = self._moments()
+        ck = {"format": 1, "extractor": "attention" if isinstance(self.q.features, AttentionFeatures) else "mlp", "n_stack": self.k, "obs_dim": self.D,
+              "q": {k_: v.detach().clone() for k_, v in self.q.state_dict().items()},
+              "q_target": {k_: v.detach().clone() for k_, v in self.q_target.state_dict().items()},
+              "exp_avg": {k_: m[0].detach().clone() for k_, m in moments.items()},
+              "exp_avg_sq": {k_: m[1].detach().clone() for k_, m in moments.items()},
+              "optimizer_step": step, "num_timesteps": self.num_timesteps, "n_calls": self.n_calls, "n_updates": self.n_updates,
+              "total_timesteps": self.total_timesteps, "generator_state": self.gen.get_state(),
+              "act_counter": float(self._act_counter) if self.__dict__.get("_act_counter") is not None else 0.0}
+        tmp = f"{path}.{os.getpid()}.tmp"
+        torch.save(ck, tmp)
+        os.replace(tmp, path)
+
+    def load(self, path):
+        """Restore `save`'s file into this learner (same architecture; either update path may have written it).  In place: the
+        captured graphs, the fused inference weight blocks' addresses and the library's flat buffers stay valid."""
+        ck = torch.load(path, map_location=self.dev, weights_only=True)
+        assert ck["format"] == 1 and ck["n_stack"] == self.k and ck["obs_dim"] == self.D, "checkpoint of another configuration"
+        self.q.load_state_dict(ck["q"])
+        self.q_target.load_state_dict(ck["q_target"])
+        if self._mlp is None and not self.opt.state:         # torch Adam creates its state at the first step: create it now
+            for p in self.q.parameters():
+                p.grad = torch.zeros_like(p)
+            lr = [g["lr"].clone() if torch.is_tensor(g["lr"]) else g["lr"] for g in self.opt.param_groups]
+            self._set_lr(0.0)
+            self.opt.step()                                    # (learning rate 0, zero gradients: changes nothing but the state)
+            for g, v in zip(self.opt.param_groups, lr):
+                (g["lr"].copy_(v) if torch.is_tensor(g["lr"]) else g.__setitem__("lr", v))
+            self.opt.zero_grad(set_to_none=True)
+        moments, _ = self._moments()
+        for name, (m1, m2) in moments.items():
+            m1.copy_(ck["exp_avg"][name]); m2.copy_(ck["exp_avg_sq"][name])
+        if self._mlp is not None:
+            self._mlp.scalars[N.UPD_STEP] = float(ck["optimizer_step"])
+        else:
+            for st in self.opt.state.values():
+                st["step"].fill_(float(ck["optimizer_step"])) if torch.is_tensor(st["step"]) else st.__setitem__("step", ck["optimizer_step"])
+        self.num_timesteps, self.n_calls, self.n_updates = int(ck["num_timesteps"]), int(ck["n_calls"]), int(ck["n_updates"])
+        self.gen.set_state(ck["generator_state"].cpu())
+        if self.__dict__.get("_act_counter") is None:
+            self._act_counter = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        self._act_counter.fill_(float(ck["act_counter"]))
+        if self._fused is not None:
+            self._fused.refresh(self.q.features)
         return self
 
     # ---- evaluation -----------------------------------------------------------------------------------

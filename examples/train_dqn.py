@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--tune-gemms", action="store_true", help="let PyTorch's TunableOp pick the update's GEMM kernels even without a cache (seconds of tuning, persisted under $UAVENV_CACHE_DIR; by default a cache is used when present)")
     ap.add_argument("--updates-per-transition", type=float, default=None, help="e.g. 0.0625 = the reference's one update per 16 transitions (overrides --gradient-steps)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--save", default=None, help="write the learner's checkpoint here at the end (networks, Adam state, counters: the reference's model.save)")
+    ap.add_argument("--load", default=None, help="resume from a checkpoint written by --save (--timesteps is then the TOTAL to reach)")
     args = ap.parse_args()
 
     flags = 0
@@ -50,6 +52,8 @@ def main():
     env = U.BatchedUAVEnv(args.envs, flags=flags, **kw)
     hp = dict(REFERENCE_HYPERPARAMS, n_stack=args.n_stack, total_timesteps=args.timesteps, gradient_steps=args.gradient_steps)
     learner = DQNLearner(env, extractor=args.extractor, seed=args.seed, reward_scale=args.reward_scale, updates_per_transition=args.updates_per_transition, tune_gemms=True if args.tune_gemms else None, **hp)
+    if args.load:
+        learner.load(args.load)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     half = {}
@@ -61,6 +65,8 @@ def main():
     learner.learn(callback=mark)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
+    if args.save:
+        learner.save(args.save)
     dt = t1 - t0
     st = env.episode_stats()
     done_eps = st[st["valid"] == 1]

@@ -26,6 +26,15 @@ def test_train_dqn_example_both_update_ratios():
     assert d["updates_per_transition"] == 0.0625 and d["gradient_steps"] >= 0.9 * (40000 - 25000) / 16   # one update per 16 transitions
 
 
+def test_train_dqn_example_saves_and_resumes(tmp_path):
+    ck = str(tmp_path / "dqn.pt")
+    a = _run("train_dqn.py", "--envs", "256", "--sensors", "20", "--timesteps", "30000", "--save", ck)
+    assert os.path.exists(ck) and a["timesteps"] >= 30000
+    b = _run("train_dqn.py", "--envs", "256", "--sensors", "20", "--timesteps", "45000", "--load", ck)
+    # resumed at a's counters: reaches the new total in (45000 - 30000) / 256 more vector steps, and keeps a's update count
+    assert b["timesteps"] >= 45000 and b["vector_steps"] == -(-45000 // 256) and b["gradient_steps"] > a["gradient_steps"]
+
+
 def test_learn_config3_example_reports_all_four_policies():
     d = _run("learn_config3.py", "--envs", "64", "--eval-envs", "64", "--timesteps", "40000", "--no-tune")
     assert d["train"]["updates_per_transition"] == 0.0625 and d["train"]["updates"] > 800

@@ -354,3 +354,53 @@ def test_two_rank_learner_on_one_gpu_graphs_coexist_with_the_exchange():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, []), (1, [])], res
+
+
+@pytest.mark.parametrize("extractor,fused_a,fused_b", [("mlp", True, True), ("mlp", True, False), ("mlp", False, True), ("attention", True, True),
+                                                       ("attention", False, True)])
+def test_checkpoint_round_trip_between_learners_and_update_paths(tmp_path, extractor, fused_a, fused_b):
+    """DQNLearner.save / load (the reference's model.save / DQN.load): a learner that trained for a while, saved, and a FRESH
+    learner that loads the file -- possibly with the other update path (library kernels <-> PyTorch) -- hold the same networks,
+    Adam state and counters, act identically on the same observations, and make the same next update on the same batch."""
+    torch, U, LR = _mods()
+    k = 4 if extractor == "mlp" else 3
+    def make(fused, seed):
+        env = U.BatchedUAVEnv(96, num_sensors=50 if extractor == "attention" else 10, max_steps=9, grid_size=(60, 60), seed=5)
+        return env, LR.DQNLearner(env, learning_rate=1e-3, buffer_size=96 * 40, batch_size=64, gamma=0.9, learning_starts=0,
+                                  target_update_interval=96 * 7, train_freq=2, gradient_steps=1, net_arch=(32, 16), n_stack=k,
+                                  total_timesteps=10**6, max_grad_norm=0.5, seed=seed, reward_scale=1e-3, extractor=extractor,
+                                  fused_update=fused, use_graphs=False)
+    env_a, A = make(fused_a, 3)
+    for _ in range(12):
+        A.collect(A.train_freq); A.train()
+    path = str(tmp_path / "dqn.pt")
+    A.save(path)
+    ck = torch.load(path, weights_only=True)                            # plain tensors and numbers only
+    assert ck["n_updates"] == A.n_updates > 5 and ck["optimizer_step"] == A.n_updates
+    env_b, B = make(fused_b, 99)                                         # other initial weights, other generator
+    assert any(not torch.equal(a, b) for a, b in zip(A.q.parameters(), B.q.parameters()))
+    B.load(path)
+    for a, b in zip(list(A.q.parameters()) + list(A.q_target.parameters()), list(B.q.parameters()) + list(B.q_target.parameters())):
+        assert torch.equal(a, b)
+    ma, sa = A._moments(); mb, sb = B._moments()
+    assert sa == sb == A.n_updates and set(ma) == set(mb)
+    for name in ma:
+        assert torch.equal(ma[name][0], mb[name][0]) and torch.equal(ma[name][1], mb[name][1]), name
+    assert (B.num_timesteps, B.n_calls, B.n_updates) == (A.num_timesteps, A.n_calls, A.n_updates)
+    assert B.exploration_rate() == A.exploration_rate() and torch.equal(A.gen.get_state(), B.gen.get_state())
+    x = A._stacked.clone()
+    with torch.no_grad():                                               # (same weights at other addresses: the GEMM library may pick another kernel)
+        assert torch.allclose(A.q(x), B.q(x), rtol=1e-5, atol=1e-6)
+    # the same next update on the same batch (A's ring), each with its own update path
+    batch = {k_: (v.clone() if torch.is_tensor(v) else v) for k_, v in A._sample().items()}
+    for L in (A, B):
+        L._set_lr(1e-3)
+        L._backward(batch); L._apply()
+    lr = 1e-3
+    for (name, a), b in zip(A.q.named_parameters(), B.q.parameters()):
+        d = float((a.detach() - b.detach()).abs().max())
+        assert d <= (1e-6 if fused_a == fused_b else 2.0 * lr), (name, d)
+    with torch.no_grad():
+        qa, qb = A.q(x), B.q(x)
+    assert torch.allclose(qa, qb, rtol=1e-3, atol=1e-3 * float(qa.abs().max()) + 1e-6)
+    env_a.close(); env_b.close()
