@@ -145,3 +145,42 @@ def test_two_rank_learner_keeps_replicas_identical_and_shares_the_ring(replicate
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_checkpoint_round_trip_on_the_cpu_doubles(tmp_path):
+    """DQNLearner.save / load with the PyTorch update path on CPU stand-ins for the environment and the frame stack: a fresh learner
+    (no optimiser state yet) that loads the file holds the saver's networks, Adam moments / step and counters, and makes the
+    same next update on the same batch."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from learner_doubles import ToyEnv, TorchFrameStack
+    E, D, k = 6, 12, 3
+
+    def make(seed):
+        return LR.DQNLearner(ToyEnv(E, D, rank=0, period=7), learning_rate=1e-2, buffer_size=E * 40, batch_size=32, gamma=0.9,
+                             learning_starts=0, target_update_interval=E * 6, train_freq=4, gradient_steps=1, net_arch=(16, 8), n_stack=k,
+                             total_timesteps=10**6, seed=seed, chunk_len=4, frame_stack_cls=TorchFrameStack)
+    A = make(11)
+    A.learn(total_timesteps=E * 4 * 7)
+    assert A.n_updates >= 5
+    path = str(tmp_path / "dqn.pt")
+    A.save(path)
+    ck = torch.load(path, weights_only=True)
+    assert ck["optimizer_step"] == A.n_updates and set(ck["exp_avg"]) == set(dict(A.q.named_parameters()))
+    B = make(5)
+    assert not B.opt.state                                   # Adam's state does not exist before a step: load creates it
+    B.load(path)
+    for a, b in zip(list(A.q.parameters()) + list(A.q_target.parameters()), list(B.q.parameters()) + list(B.q_target.parameters())):
+        assert torch.equal(a, b)
+    ma, sa = A._moments(); mb, sb = B._moments()
+    assert sa == sb == A.n_updates
+    for name in ma:
+        assert torch.equal(ma[name][0], mb[name][0]) and torch.equal(ma[name][1], mb[name][1]), name
+    assert (B.num_timesteps, B.n_calls, B.n_updates) == (A.num_timesteps, A.n_calls, A.n_updates)
+    assert torch.equal(A.gen.get_state(), B.gen.get_state())
+    batch = A._sample()
+    for L in (A, B):
+        L._set_lr(1e-2)
+        L._backward(batch); L._apply()
+    for a, b in zip(A.q.parameters(), B.q.parameters()):
+        assert torch.equal(a, b)
