@@ -346,6 +346,22 @@ class DQNLearner:
             else:
                 g["lr"] = lr
 
+    @torch.no_grad()
+    def _sync_target(self):
+        """SB3's hard target update (tau = 1), in place.  With the library's update the layers' parameters are two flat buffers: ONE
+        contiguous copy (4 us) where a multi-tensor copy over their eight tensors is 11 us -- at 4096 environments
+        target_update_interval 5000 means after EVERY vector step."""
+        if self.__dict__.get("_sync_lists") is None:
+            if self._mlp is not None:
+                src, dst = list(self.q.features.parameters()), list(self.q_target.features.parameters())
+            else:
+                src, dst = list(self.q.parameters()), list(self.q_target.parameters())
+            self._sync_lists = ([t for t in dst] + list(self.q_target.buffers()), [t.detach() for t in src] + list(self.q.buffers()))
+        if self._mlp is not None:
+            self._mlp.sync_target()
+        if self._sync_lists[0]:
+            torch._foreach_copy_(self._sync_lists[0], self._sync_lists[1])
+
     def _after_vector_step(self):
         self.num_timesteps += self.n_envs_total
         self.n_calls += 1
@@ -355,8 +371,6 @@ class DQNLearner:
         stack, copy the target network when it is due every step.  All graphs share one memory pool (they never overlap)."""
         ring, E = self.ring, self.E
         self._g_eps = torch.zeros((), device=self.dev)
-        self._g_tp = [p for p in self.q_target.parameters()] + [b for b in self.q_target.buffers()]
-        self._g_sp = [p.detach() for p in self.q.parameters()] + [b for b in self.q.buffers()]
         # the attention extractor acts through the fused inference kernel (csrc/uavenv_attention.hip: one launch of ~50 us for
         # 4096 stacked observations where the eager module spends ~860 us of GPU time); its weight block is re-packed after
         # every update (train graph / eager train)
@@ -386,7 +400,7 @@ class DQNLearner:
                     o, _, d = self.env.step(actions, obs_out=ring.local_obs_slot(slot))
                     self.fs.step(o, d, None)
                     if self.target_every == 1:
-                        torch._foreach_copy_(self._g_tp, self._g_sp)
+                        self._sync_target()
                 finally:
                     g.capture_end()
                 graphs[slot] = g
@@ -560,7 +574,7 @@ class DQNLearner:
                 self.ring._point_env()
                 self._after_vector_step()
                 if self.target_every != 1 and self.n_calls % self.target_every == 0:
-                    self.q_target.load_state_dict(self.q.state_dict())
+                    self._sync_target()
                 continue
             actions = self.act(self._stacked, self.exploration_rate())
             o, _, d = self.env.step(actions, obs_out=self.ring.local_obs_slot())
@@ -570,7 +584,7 @@ class DQNLearner:
             self.n_calls += 1
             self._warm_act += 1
             if self.n_calls % self.target_every == 0:
-                self.q_target.load_state_dict(self.q.state_dict())
+                self._sync_target()
 
     # ---- learning -------------------------------------------------------------------------------------
     def train(self, gradient_steps=None):
