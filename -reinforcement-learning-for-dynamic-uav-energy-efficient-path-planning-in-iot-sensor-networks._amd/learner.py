@@ -140,6 +140,29 @@ class QNetwork(nn.Module):
     def forward(self, x):
         return self.head(self.features(x))
 
+    @torch.no_grad()
+    def head_inference(self, h):
+        """`self.head(h)` for acting (no gradients): every Linear + ReLU pair as ONE library GEMM with the bias + ReLU epilogue
+        (`torch._addmm_activation`: hipBLASLt's fused epilogue, bit-identical to Linear followed by ReLU) -- eager PyTorch runs the
+        ReLU as a launch of its own over the [envs x width] activations: 3 x 6.5 us of a 144 us vector step at 4096 environments."""
+        mods = list(self.head)
+        fused = h.is_cuda and hasattr(torch, "_addmm_activation")
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if fused and isinstance(m, nn.Linear) and m.bias is not None and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
+                h = torch._addmm_activation(m.bias, h, m.weight.t())
+                i += 2
+            else:
+                h = m(h)
+                i += 1
+        return h
+
+    @torch.no_grad()
+    def q_inference(self, x, features=None):
+        """Q-values for acting: `features` (optional) replaces the extractor's module forward (the fused attention kernel)."""
+        return self.head_inference(self.features(x) if features is None else features(x))
+
 
 def tunable_cache_path(device):
     """Where the TunableOp results for `device` are kept: $UAVENV_CACHE_DIR (default ~/.cache/uavenv_amd) /
@@ -322,8 +345,8 @@ class DQNLearner:
             if self.__dict__.get("_eps_eager") is None:
                 self._eps_eager = torch.zeros((), device=self.dev)
             self._eps_eager.fill_(float(epsilon))
-            return self._select_actions(self.q(stacked), self._eps_eager)
-        greedy = self.q(stacked).argmax(1).to(torch.int32)
+            return self._select_actions(self.q.q_inference(stacked), self._eps_eager)
+        greedy = self.q.q_inference(stacked).argmax(1).to(torch.int32)
         if epsilon <= 0.0:
             return greedy
         rnd = torch.randint(0, 5, (self.E,), device=self.dev, dtype=torch.int32, generator=self.gen)
@@ -380,7 +403,7 @@ class DQNLearner:
             self._fused = FusedAttentionFeatures(self.q.features, self.k, self.dev)
 
         def q_values(x):
-            return self.q.head(self._fused(x)) if self._fused is not None else self.q(x)
+            return self.q.q_inference(x, self._fused)
         pool = torch.cuda.graph_pool_handle()
         graphs = [None] * ring.capacity
         torch.cuda.synchronize(self.dev)
@@ -718,7 +741,7 @@ class DQNLearner:
         while bool((done_count < episodes_per_env).any()) and guard < 100000:
             guard += 1
             if policy == "greedy":
-                a = self.q(stacked).argmax(1).to(torch.int32)
+                a = self.q.q_inference(stacked).argmax(1).to(torch.int32)
             else:
                 a = torch.randint(0, 5, (E,), device=self.dev, dtype=torch.int32, generator=gen)
             o, r, d = eval_env.step(a)
@@ -747,7 +770,7 @@ class DQNLearner:
         gen = torch.Generator(device=self.dev).manual_seed(12345)
         for _ in range(max_steps):
             if policy == "greedy":
-                a = self.q(stacked).argmax(1).to(torch.int32)
+                a = self.q.q_inference(stacked).argmax(1).to(torch.int32)
                 o, r, d = eval_env.step(a)
             elif policy == "random":
                 o, r, d = eval_env.step(torch.randint(0, 5, (E,), device=self.dev, dtype=torch.int32, generator=gen))

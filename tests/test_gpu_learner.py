@@ -404,3 +404,24 @@ def test_checkpoint_round_trip_between_learners_and_update_paths(tmp_path, extra
         qa, qb = A.q(x), B.q(x)
     assert torch.allclose(qa, qb, rtol=1e-3, atol=1e-3 * float(qa.abs().max()) + 1e-6)
     env_a.close(); env_b.close()
+
+
+def test_acting_forward_with_fused_bias_relu_epilogues_equals_the_module():
+    """QNetwork.head_inference (Linear + ReLU pairs as one GEMM with the bias + ReLU epilogue) against the module it replaces for
+    acting, at the reference's widths and at 4096 rows: the same Q-values (to fp32 summation order) and the same greedy actions."""
+    torch, U, LR = _mods()
+    torch.manual_seed(1)
+    q = LR.QNetwork(153, 4).cuda()
+    x = torch.rand(4096, 612, device="cuda")
+    with torch.no_grad():
+        want = q(x)
+    got = q.q_inference(x)
+    assert got.shape == want.shape == (4096, 5)
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-6), float((got - want).abs().max())
+    top2 = want.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-5
+    assert int(clear.sum()) > 3000 and torch.equal(got.argmax(1)[clear], want.argmax(1)[clear])
+    q1 = LR.QNetwork(7, 3, (16,)).cuda()                                 # one hidden layer, odd widths
+    x1 = torch.randn(33, 21, device="cuda")
+    with torch.no_grad():
+        assert torch.allclose(q1.q_inference(x1), q1(x1), rtol=1e-5, atol=1e-6)
