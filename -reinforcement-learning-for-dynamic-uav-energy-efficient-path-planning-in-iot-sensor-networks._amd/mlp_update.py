@@ -23,8 +23,11 @@ def _p(t):
 class FusedMLPUpdate:
     """Owns the flat parameter / gradient / Adam-state buffers of `q` (and `q_target`) and runs updates on sampled batches.
 
-    q, q_target: QNetwork with the Flatten extractor (learner.py): `head` = Linear, ReLU, ..., Linear.  Their parameters are
-    re-pointed to views of `self.flat` / `self.flat_target` (same values), so `q(x)` for acting sees every update.
+    q, q_target: QNetwork (learner.py): `head` = Linear, ReLU, ..., Linear.  The heads' parameters are re-pointed to views of
+    `self.flat` / `self.flat_target` (same values), so `q(x)` for acting sees every update.  With the Flatten extractor that is the
+    whole network; with a features extractor in front (the attention extractor) the caller runs the extractor, hands its output in
+    as `obs` / `next_obs`, continues the backward pass from `self.dx0` with autograd (`input_grad=True`) and lets this object
+    optimise the extractor's parameters as well (`extra_params`): learner.py's "hybrid" update.
     """
 
     def __init__(self, q, q_target, batch_size, gamma, max_grad_norm, reward_scale=1.0, betas=(0.9, 0.999), eps=1e-8, lr=1e-3,
