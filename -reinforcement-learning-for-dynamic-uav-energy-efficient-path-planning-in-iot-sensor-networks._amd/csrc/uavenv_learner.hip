@@ -325,6 +325,96 @@ __global__ __launch_bounds__(1024) void epsilon_greedy_kernel(const float* __res
     if (threadIdx.x == 0) counter_dev[0] = (float)(cnt + 1);
 }
 
+// The LAST layer of the acting forward (a [n_envs x K] . [K x n_actions] product with n_actions = 5: 5 us as a library GEMM) and the
+// epsilon-greedy selection above in ONE launch: a wavefront takes 16 environments, four lanes per environment split K in 16-byte
+// pieces (a row's four lanes read 64 contiguous bytes per step), the weights come from LDS, the partial sums meet through two
+// lane swaps, and the environment's first lane takes the argmax, flips the coin and writes the action -- the draws are the
+// epsilon_greedy_kernel's (same Philox words per environment and call).  The draw counter is advanced by whichever workgroup
+// finishes last (a ticket counter: every workgroup has read the counter long before the last one takes its ticket).
+constexpr int kSelMaxActions = 8;
+// NA: compile-time bound of n_actions (5 for this environment; 8 otherwise -- rows past n_actions repeat the last action's weights and
+// are ignored).  Every load is unconditional with a clamped address: a load inside a branch makes the compiler wait for it at the
+// branch's end, and the 16 steps over a 256-wide row then cost 16 trips to memory instead of one (9 us instead of 4).
+template <int NA>
+__global__ __launch_bounds__(256) void q_head_select_kernel(const float* __restrict__ h, const float* __restrict__ W, const float* __restrict__ b,
+                                                          int32_t n_envs, int32_t K, int32_t n_actions, const float* __restrict__ eps_dev,
+                                                          float* __restrict__ counter_dev, int32_t* __restrict__ ticket_dev, uint64_t seed,
+                                                          int32_t shared_coin, int32_t* __restrict__ actions_out, float* __restrict__ q_out) {
+    extern __shared__ float wl[];                              // [n_actions][K], K a multiple of 4 here (the launcher checks)
+    const int total = n_actions * K;
+    {
+        f32x4 t[4];                                            // 4 x 256 threads x 4 floats = 4096 floats per pass
+        for (int base = 0; base < total; base += 4096) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = base + 4 * ((int)threadIdx.x + 256 * u); t[u] = *reinterpret_cast<const f32x4*>(W + (i < total ? i : total - 4)); }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = base + 4 * ((int)threadIdx.x + 256 * u); if (i < total) *reinterpret_cast<f32x4*>(&wl[i]) = t[u]; }
+        }
+    }
+    const uint64_t cnt = (uint64_t)counter_dev[0];
+    const float eps = eps_dev[0];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int part = lane & 3;
+    const int e = (blockIdx.x * 4 + wave) * 16 + (lane >> 2);
+    const bool live = e < n_envs;
+    const float* row = h + (size_t)(live ? e : n_envs - 1) * K;
+    float acc[NA];
+#pragma unroll
+    for (int a = 0; a < NA; a++) acc[a] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 256) {                      // 16 steps of 16 floats per pass
+        f32x4 x[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) { const int k = k0 + 16 * i + 4 * part; x[i] = *reinterpret_cast<const f32x4*>(row + (k < K ? k : K - 4)); }
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int k = k0 + 16 * i + 4 * part;
+            const bool in = k < K;
+            const int kc = in ? k : K - 4;
+#pragma unroll
+            for (int a = 0; a < NA; a++) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(&wl[(a < n_actions ? a : n_actions - 1) * K + kc]);
+                const float p = (x[i].x * w.x + x[i].y * w.y) + (x[i].z * w.z + x[i].w * w.w);
+                acc[a] += in ? p : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < NA; a++) {
+        acc[a] += __shfl_xor(acc[a], 1);
+        acc[a] += __shfl_xor(acc[a], 2);
+    }
+    if (live && part == 0) {
+        int best = 0; float bv = 0.f;
+#pragma unroll
+        for (int a = 0; a < NA; a++) {
+            if (a < n_actions) {
+                const float v = acc[a] + b[a];
+                if (q_out != nullptr) q_out[(size_t)e * n_actions + a] = v;
+                if (a == 0 || v > bv) { bv = v; best = a; }      // first maximum, like torch.argmax
+            }
+        }
+        const uavenv::Words4 w = uavenv::philox4x32<UAVENV_PHILOX_ROUNDS>((uint32_t)e, (uint32_t)cnt, (uint32_t)(cnt >> 32), 0x45505347u,
+                                                                         (uint32_t)seed, (uint32_t)(seed >> 32));
+        uint32_t coin_word = w.w0;
+        if (shared_coin)
+            coin_word = uavenv::philox4x32<UAVENV_PHILOX_ROUNDS>(0xFFFFFFFFu, (uint32_t)cnt, (uint32_t)(cnt >> 32), 0x45505347u,
+                                                               (uint32_t)seed, (uint32_t)(seed >> 32)).w0;
+        const int rnd = (int)uavenv::mulhi32(w.w1, (uint32_t)n_actions);
+        actions_out[e] = uavenv::u24(coin_word) < eps ? rnd : best;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // (relaxed: nothing but the ticket travels between workgroups -- this workgroup's read of the counter completed long ago,
+        //  its value went into every draw above; an acquire / release here would write back and invalidate the XCD's L2 per workgroup)
+        const int t = __hip_atomic_fetch_add(ticket_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == (int)gridDim.x - 1) {                         // the last workgroup of the launch
+            __hip_atomic_store(ticket_dev, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            counter_dev[0] = (float)(cnt + 1);
+        }
+    }
+}
+
 }  // namespace
 
 // replaces: the three matrix products of torch.nn.Linear's forward / backward at DQN batch sizes (dqn.py:1086 batch_size 256).
@@ -402,5 +492,27 @@ extern "C" int uavenv_epsilon_greedy(const float* q_dev, int32_t n_envs, int32_t
     if (!q_dev || !eps_dev || !counter_dev || !actions_out_dev || n_envs < 1 || n_actions < 1) return UAVENV_E_INVALID;
     epsilon_greedy_kernel<<<dim3(1), dim3(1024), 0, (hipStream_t)stream>>>(q_dev, n_envs, n_actions, eps_dev, counter_dev, seed, shared_coin,
                                                                         actions_out_dev);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_E_HIP;
+}
+
+// replaces: the last Linear of the acting forward + uavenv_epsilon_greedy in one launch: h_dev float [n_envs][K] (the last hidden
+// layer's activations, ReLU applied), w_dev float [n_actions][K], b_dev float [n_actions] (torch.nn.Linear's layout), n_actions <= 8,
+// K a multiple of 4, both 16-byte aligned, n_actions * K * 4 bytes of LDS (<= 64 KB); *counter_dev as in uavenv_epsilon_greedy (same draws for the same counter and seed);
+// ticket_dev int32 [1], zero before the first call (the kernel leaves it zero); q_out_dev float [n_envs][n_actions], nullable.
+extern "C" int uavenv_q_head_select(const float* h_dev, const float* w_dev, const float* b_dev, int32_t n_envs, int32_t k, int32_t n_actions,
+                                    const float* eps_dev, float* counter_dev, int32_t* ticket_dev, uint64_t seed, int32_t shared_coin,
+                                    int32_t* actions_out_dev, float* q_out_dev, void* stream) {
+    if (!h_dev || !w_dev || !b_dev || !eps_dev || !counter_dev || !ticket_dev || !actions_out_dev || n_envs < 1 || k < 1 || n_actions < 1 ||
+        n_actions > kSelMaxActions || (long)n_actions * k * 4 > 65536) return UAVENV_E_INVALID;
+    if ((k & 3) != 0 || (reinterpret_cast<uintptr_t>(h_dev) & 15) || (reinterpret_cast<uintptr_t>(w_dev) & 15)) return UAVENV_E_INVALID;
+    const unsigned wgs = (unsigned)((n_envs + 63) / 64);
+    const size_t lds = (size_t)n_actions * k * sizeof(float);
+    if (n_actions <= 5)
+        q_head_select_kernel<5><<<dim3(wgs), dim3(256), lds, (hipStream_t)stream>>>(h_dev, w_dev, b_dev, n_envs, k, n_actions, eps_dev, counter_dev,
+                                                                                ticket_dev, seed, shared_coin, actions_out_dev, q_out_dev);
+    else
+        q_head_select_kernel<kSelMaxActions><<<dim3(wgs), dim3(256), lds, (hipStream_t)stream>>>(h_dev, w_dev, b_dev, n_envs, k, n_actions, eps_dev,
+                                                                                             counter_dev, ticket_dev, seed, shared_coin,
+                                                                                             actions_out_dev, q_out_dev);
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_E_HIP;
 }

@@ -141,11 +141,11 @@ class QNetwork(nn.Module):
         return self.head(self.features(x))
 
     @torch.no_grad()
-    def head_inference(self, h):
+    def head_inference(self, h, upto_last=False):
         """`self.head(h)` for acting (no gradients): every Linear + ReLU pair as ONE library GEMM with the bias + ReLU epilogue
         (`torch._addmm_activation`: hipBLASLt's fused epilogue, bit-identical to Linear followed by ReLU) -- eager PyTorch runs the
         ReLU as a launch of its own over the [envs x width] activations: 3 x 6.5 us of a 144 us vector step at 4096 environments."""
-        mods = list(self.head)
+        mods = list(self.head)[:-1] if upto_last else list(self.head)      # upto_last: stop in front of the output layer
         fused = h.is_cuda and hasattr(torch, "_addmm_activation")
         i = 0
         while i < len(mods):
@@ -339,13 +339,41 @@ class DQNLearner:
             raise RuntimeError(f"uavenv_epsilon_greedy failed ({rc})")
         return self._act_out
 
+    def _act_device(self, x, eps_dev, features=None):
+        """Actions for a vector of stacked observations on the GPU: the network up to its last hidden layer through the library
+        GEMMs, then the output layer + epsilon-greedy selection in ONE launch (uavenv_q_head_select: the [envs x 256] . [256 x 5]
+        product was 5 us as a library GEMM, the selection 6 us as a launch of its own)."""
+        import ctypes as C
+        f = self.q.features(x) if features is None else features(x)
+        last = self.q.head[-1]
+        if not (isinstance(last, nn.Linear) and last.bias is not None and last.out_features <= 8 and last.in_features % 4 == 0
+                and last.in_features * last.out_features <= 16384 and last.weight.data_ptr() % 16 == 0):
+            return self._select_actions(self.q.head_inference(f), eps_dev)
+        h = self.q.head_inference(f, upto_last=True).contiguous()
+        if self.__dict__.get("_act_out") is None:
+            self._act_out = torch.zeros(self.E, dtype=torch.int32, device=self.dev)
+            if self.__dict__.get("_act_counter") is None:      # (a checkpoint may have put it there already)
+                self._act_counter = torch.zeros(1, dtype=torch.float32, device=self.dev)
+            self._alib = N.lib()
+        if self.__dict__.get("_act_ticket") is None:
+            self._act_ticket = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        rc = self._alib.uavenv_q_head_select(C.c_void_p(h.data_ptr()), C.c_void_p(last.weight.data_ptr()), C.c_void_p(last.bias.data_ptr()),
+                                             self.E, last.in_features, last.out_features, C.c_void_p(eps_dev.data_ptr()),
+                                             C.c_void_p(self._act_counter.data_ptr()), C.c_void_p(self._act_ticket.data_ptr()),
+                                             (self._sample_seed * 2654435761 + 97) & 0xFFFFFFFFFFFFFFFF, 1 if self.shared_coin else 0,
+                                             C.c_void_p(self._act_out.data_ptr()), None,
+                                             C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream))
+        if rc:
+            raise RuntimeError(f"uavenv_q_head_select failed ({rc})")
+        return self._act_out
+
     @torch.no_grad()
     def act(self, stacked, epsilon):
         if self.dev.type == "cuda":
             if self.__dict__.get("_eps_eager") is None:
                 self._eps_eager = torch.zeros((), device=self.dev)
             self._eps_eager.fill_(float(epsilon))
-            return self._select_actions(self.q.q_inference(stacked), self._eps_eager)
+            return self._act_device(stacked, self._eps_eager)
         greedy = self.q.q_inference(stacked).argmax(1).to(torch.int32)
         if epsilon <= 0.0:
             return greedy
@@ -402,8 +430,6 @@ class DQNLearner:
             from .attention import FusedAttentionFeatures
             self._fused = FusedAttentionFeatures(self.q.features, self.k, self.dev)
 
-        def q_values(x):
-            return self.q.q_inference(x, self._fused)
         pool = torch.cuda.graph_pool_handle()
         graphs = [None] * ring.capacity
         torch.cuda.synchronize(self.dev)
@@ -419,7 +445,7 @@ class DQNLearner:
                 g.capture_begin(pool=pool)
                 try:
                     ring._point_env(slot)
-                    actions = self._select_actions(q_values(self.fs.stacked), self._g_eps)
+                    actions = self._act_device(self.fs.stacked, self._g_eps, self._fused)
                     o, _, d = self.env.step(actions, obs_out=ring.local_obs_slot(slot))
                     self.fs.step(o, d, None)
                     if self.target_every == 1:

@@ -385,6 +385,16 @@ int uavenv_clip_adam(float* param_dev, const float* grad_dev, float* exp_avg_dev
 int uavenv_epsilon_greedy(const float* q_dev, int32_t n_envs, int32_t n_actions, const float* eps_dev, float* counter_dev,
                           uint64_t seed, int32_t shared_coin, int32_t* actions_out_dev, void* stream);
 
+/* replaces: the LAST Linear layer of the acting forward (dqn.py:1078 policy "MlpPolicy": n_actions outputs) and
+ * uavenv_epsilon_greedy in one launch.  h_dev float [n_envs][k]: the last hidden layer's activations; w_dev float [n_actions][k],
+ * b_dev float [n_actions] (torch.nn.Linear's layout); n_actions <= 8, k a multiple of 4 (h_dev, w_dev 16-byte aligned),
+ * n_actions * k <= 16384.  Draws and *counter_dev as in
+ * uavenv_epsilon_greedy (the same actions for the same Q-values, counter and seed); ticket_dev int32 [1]: zero before the first call,
+ * left zero by every call; q_out_dev float [n_envs][n_actions] (nullable) receives the Q-values. */
+int uavenv_q_head_select(const float* h_dev, const float* w_dev, const float* b_dev, int32_t n_envs, int32_t k, int32_t n_actions,
+                         const float* eps_dev, float* counter_dev, int32_t* ticket_dev, uint64_t seed, int32_t shared_coin,
+                         int32_t* actions_out_dev, float* q_out_dev, void* stream);
+
 /* ---- state access (checkpoint / parity / the attribute reads of SURVEY 1) -------------------- */
 /* Copies one whole field.  `bytes` must equal the field size; dst/src may be host or device.
  * A state handed to uavenv_set_state must be one the library could have produced: 0 <= data_buffer <= max_buffer_size in every

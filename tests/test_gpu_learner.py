@@ -425,3 +425,49 @@ def test_acting_forward_with_fused_bias_relu_epilogues_equals_the_module():
     x1 = torch.randn(33, 21, device="cuda")
     with torch.no_grad():
         assert torch.allclose(q1.q_inference(x1), q1(x1), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("shared", [False, True], ids=["own_coins", "shared_coin"])
+def test_output_layer_and_selection_in_one_launch_equal_the_two_step_form(shared):
+    """uavenv_q_head_select (last Linear + epsilon-greedy in one launch, what acting runs) against the library GEMM followed by
+    uavenv_epsilon_greedy at the same draw counter: the same coins and random actions per environment, the same greedy actions where
+    the two summation orders cannot flip the argmax; both advance the counter by one; 300 environments (not a multiple of 64)."""
+    torch, U, LR = _mods()
+    from uavenv_amd import _native as N
+    import ctypes as C
+    env = U.BatchedUAVEnv(300, num_sensors=10, seed=3)
+    L = LR.DQNLearner(env, learning_rate=1e-3, buffer_size=300 * 20, batch_size=64, learning_starts=0, net_arch=(64, 256), n_stack=4,
+                      total_timesteps=10**6, seed=4, shared_exploration_coin=shared, use_graphs=False)
+    L.collect(3)
+    x = L._stacked.clone()
+    eps = torch.tensor(0.35, device=L.dev)
+    for c0 in (7.0, 8.0):
+        L._act_counter.fill_(c0)
+        with torch.no_grad():
+            q = L.q.q_inference(x)
+        a_two = L._select_actions(q, eps).clone()
+        assert float(L._act_counter) == c0 + 1
+        L._act_counter.fill_(c0)
+        a_one = L._act_device(x, eps).clone()
+        assert float(L._act_counter) == c0 + 1 and int(L._act_ticket) == 0
+        top2 = q.topk(2, dim=1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 1e-5
+        assert int(clear.sum()) > 250 and torch.equal(a_one[clear], a_two[clear])
+        greedy = q.argmax(1).to(torch.int32)
+        explored = a_two != greedy
+        assert 40 < int(explored.sum()) < 150 or shared          # ~0.35 * 4/5 of 300 take another action (one coin: all or none)
+    # the Q-values it computes, on request
+    qo = torch.zeros(300, 5, device=L.dev)
+    last = L.q.head[-1]
+    h = L.q.head_inference(L.q.features(x), upto_last=True).contiguous()
+    rc = N.lib().uavenv_q_head_select(C.c_void_p(h.data_ptr()), C.c_void_p(last.weight.data_ptr()), C.c_void_p(last.bias.data_ptr()), 300, 256, 5,
+                                      C.c_void_p(eps.data_ptr()), C.c_void_p(L._act_counter.data_ptr()), C.c_void_p(L._act_ticket.data_ptr()), 1, 0,
+                                      C.c_void_p(L._act_out.data_ptr()), C.c_void_p(qo.data_ptr()), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.allclose(qo, q, rtol=1e-5, atol=1e-6)
+    # bad arguments
+    assert N.lib().uavenv_q_head_select(C.c_void_p(h.data_ptr()), C.c_void_p(last.weight.data_ptr()), C.c_void_p(last.bias.data_ptr()), 300, 256, 9,
+                                        C.c_void_p(eps.data_ptr()), C.c_void_p(L._act_counter.data_ptr()), C.c_void_p(L._act_ticket.data_ptr()), 1, 0,
+                                        C.c_void_p(L._act_out.data_ptr()), None, None) == N.E_INVALID
+    env.close()
