@@ -251,7 +251,8 @@ class DQNLearner:
             self._hybrid = extractor != "mlp"
             self._mlp = FusedMLPUpdate(self.q, self.q_target, self.local_batch, self.gamma, self.max_grad_norm, self.reward_scale,
                                        lr=self.lr_schedule(1.0), input_grad=self._hybrid,
-                                       extra_params=list(self.q.features.parameters()) if self._hybrid else ())
+                                       extra_params=list(self.q.features.parameters()) if self._hybrid else (),
+                                       extra_target_params=list(self.q_target.features.parameters()) if self._hybrid else ())
             self.opt = None                                   # (every parameter now belongs to the library's optimiser)
         self.use_graphs = on_gpu if use_graphs is None else bool(use_graphs)
         self._act_graphs, self._train_graph, self._train_graph_b, self._fused = None, None, None, None
@@ -403,8 +404,8 @@ class DQNLearner:
         contiguous copy (4 us) where a multi-tensor copy over their eight tensors is 11 us -- at 4096 environments
         target_update_interval 5000 means after EVERY vector step."""
         if self.__dict__.get("_sync_lists") is None:
-            if self._mlp is not None:
-                src, dst = list(self.q.features.parameters()), list(self.q_target.features.parameters())
+            if self._mlp is not None:                         # (its flat buffers hold every parameter; buffers, if any, go one by one)
+                src, dst = [], []
             else:
                 src, dst = list(self.q.parameters()), list(self.q_target.parameters())
             self._sync_lists = ([t for t in dst] + list(self.q_target.buffers()), [t.detach() for t in src] + list(self.q.buffers()))

@@ -31,7 +31,7 @@ class FusedMLPUpdate:
     """
 
     def __init__(self, q, q_target, batch_size, gamma, max_grad_norm, reward_scale=1.0, betas=(0.9, 0.999), eps=1e-8, lr=1e-3,
-                 input_grad=False, extra_params=()):
+                 input_grad=False, extra_params=(), extra_target_params=()):
         self.L = N.lib()
         self.q, self.q_target = q, q_target
         # input_grad: also produce `self.dx0`, the gradient w.r.t. the first layer's input -- a features extractor in front of
@@ -41,6 +41,10 @@ class FusedMLPUpdate:
         # the same flat buffers, their `.grad` views of the flat gradient buffer that autograd accumulates into (zeroed by
         # `zero_extra_grads`), so that ONE clip + Adam launch covers the whole network
         self.extra = list(extra_params)
+        # extra_target_params: the target network's copies of them, in the same order: they join `flat_target`, so that the hard
+        # target update stays ONE contiguous copy
+        self.extra_t = list(extra_target_params)
+        assert not self.extra_t or [p.shape for p in self.extra_t] == [p.shape for p in self.extra]
         self.layers = [m for m in q.head if isinstance(m, nn.Linear)]
         self.layers_t = [m for m in q_target.head if isinstance(m, nn.Linear)]
         assert len(self.layers) >= 1 and all(isinstance(m, (nn.Linear, nn.ReLU)) for m in q.head)
@@ -58,7 +62,7 @@ class FusedMLPUpdate:
         self.n_params = self.n_head + sum(p.numel() for p in self.extra)
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.flat = torch.empty(self.n_params, **f32)
-        self.flat_target = torch.empty(self.n_head, **f32)
+        self.flat_target = torch.empty(self.n_params if self.extra_t else self.n_head, **f32)
         self.exp_avg = torch.zeros(self.n_params, **f32)
         self.exp_avg_sq = torch.zeros(self.n_params, **f32)
         self.w, self.b, self.wt, self.bt, self.gw, self.gb = [], [], [], [], [], []
@@ -92,11 +96,15 @@ class FusedMLPUpdate:
                 (self.gw if name == "weight" else self.gb).append(self.grad[off:off + n].view_as(p))
                 off += n
         self.extra_grad = self.grad[off:]
-        for p in self.extra:
+        for i, p in enumerate(self.extra):
             n = p.numel()
             self.flat[off:off + n].copy_(p.detach().reshape(-1))
             p.data = self.flat[off:off + n].view_as(p)
             p.grad = self.grad[off:off + n].view_as(p)
+            if self.extra_t:
+                pt = self.extra_t[i]
+                self.flat_target[off:off + n].copy_(pt.detach().reshape(-1))
+                pt.data = self.flat_target[off:off + n].view_as(pt)
             off += n
         cur = act0
         self.z, self.zt, self.da = [], [], []
@@ -127,8 +135,8 @@ class FusedMLPUpdate:
         self.scalars[N.UPD_LR] = float(lr)
 
     def sync_target(self):
-        """SB3's hard target update (tau = 1) of the layers."""
-        self.flat_target.copy_(self.flat[:self.n_head])
+        """SB3's hard target update (tau = 1) of everything this object holds of the target network: one contiguous copy."""
+        self.flat_target.copy_(self.flat[:self.flat_target.numel()])
 
     def zero_extra_grads(self):
         """Before autograd accumulates the extra parameters' gradients (their `.grad` are views of the flat gradient buffer)."""
