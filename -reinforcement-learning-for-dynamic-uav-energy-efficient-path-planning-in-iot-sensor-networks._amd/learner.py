@@ -523,8 +523,10 @@ class DQNLearner:
             with torch.no_grad():
                 feat_next = self._target_features(batch["next_obs"])
             self._mlp.backward(dict(batch, obs=feat.detach(), next_obs=feat_next))
-            self._mlp.zero_extra_grads()
-            feat.backward(self._mlp.dx0)                       # (accumulates into views of the library's flat gradient buffer)
+            for p in self._mlp.extra:
+                p.grad = None                                  # (autograd then hands its gradient tensors over: no accumulate launches)
+            feat.backward(self._mlp.dx0)
+            self._mlp.collect_extra_grads()                    # -> the library's flat gradient buffer, one launch
             return self._mlp.loss
         if self._mlp is not None:
             self._mlp.backward(batch)

@@ -38,8 +38,8 @@ class FusedMLPUpdate:
         # the layers (the attention extractor) continues the backward pass from it with autograd
         self.input_grad = bool(input_grad)
         # extra_params: parameters OUTSIDE the layers (that extractor's) which this object optimises too -- they become views of
-        # the same flat buffers, their `.grad` views of the flat gradient buffer that autograd accumulates into (zeroed by
-        # `zero_extra_grads`), so that ONE clip + Adam launch covers the whole network
+        # the same flat buffers; after autograd has produced their gradients, `collect_extra_grads` concatenates them into the flat
+        # gradient buffer (one launch), so that ONE clip + Adam launch covers the whole network
         self.extra = list(extra_params)
         # extra_target_params: the target network's copies of them, in the same order: they join `flat_target`, so that the hard
         # target update stays ONE contiguous copy
@@ -100,7 +100,6 @@ class FusedMLPUpdate:
             n = p.numel()
             self.flat[off:off + n].copy_(p.detach().reshape(-1))
             p.data = self.flat[off:off + n].view_as(p)
-            p.grad = self.grad[off:off + n].view_as(p)
             if self.extra_t:
                 pt = self.extra_t[i]
                 self.flat_target[off:off + n].copy_(pt.detach().reshape(-1))
@@ -138,9 +137,10 @@ class FusedMLPUpdate:
         """SB3's hard target update (tau = 1) of everything this object holds of the target network: one contiguous copy."""
         self.flat_target.copy_(self.flat[:self.flat_target.numel()])
 
-    def zero_extra_grads(self):
-        """Before autograd accumulates the extra parameters' gradients (their `.grad` are views of the flat gradient buffer)."""
-        self.extra_grad.zero_()
+    def collect_extra_grads(self):
+        """The extra parameters' gradients (fresh tensors from autograd: set `.grad = None` before the backward pass, so that it
+        hands them over instead of adding them element by element into existing ones) -> the flat gradient buffer, one launch."""
+        torch.cat([p.grad.reshape(-1) for p in self.extra], out=self.extra_grad)
 
     @property
     def loss(self):
