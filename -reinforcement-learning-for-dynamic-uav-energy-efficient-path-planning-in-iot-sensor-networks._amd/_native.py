@@ -97,7 +97,7 @@ EXPORTS = [
     "uavenv_abi_version", "uavenv_default_config", "uavenv_obs_dim", "uavenv_create", "uavenv_destroy",
     "uavenv_last_error", "uavenv_num_envs", "uavenv_lane_stride", "uavenv_env_obs_dim", "uavenv_set_env_params",
     "uavenv_set_positions", "uavenv_set_seed", "uavenv_get_config", "uavenv_set_config", "uavenv_set_grid_choices", "uavenv_set_noise_tape",
-    "uavenv_dump_noise", "uavenv_reset", "uavenv_step", "uavenv_step_random", "uavenv_step_random_n", "uavenv_step_policy", "uavenv_rollout", "uavenv_frame_stack", "uavenv_ring_gather_stacked", "uavenv_ring_sample_stacked", "uavenv_set_terminal_pool", "uavenv_set_aux_output", "uavenv_enable_terminal_snapshot", "uavenv_attention_weight_floats", "uavenv_attention_features", "uavenv_gemm_f32", "uavenv_td_loss", "uavenv_clip_adam", "uavenv_epsilon_greedy", "uavenv_q_head_select", "uavenv_get_state",
+    "uavenv_dump_noise", "uavenv_reset", "uavenv_step", "uavenv_step_random", "uavenv_step_random_n", "uavenv_step_policy", "uavenv_rollout", "uavenv_frame_stack", "uavenv_ring_gather_stacked", "uavenv_ring_sample_stacked", "uavenv_set_terminal_pool", "uavenv_set_aux_output", "uavenv_enable_terminal_snapshot", "uavenv_attention_weight_floats", "uavenv_attention_features", "uavenv_gemm_f32", "uavenv_td_loss", "uavenv_clip_adam", "uavenv_epsilon_greedy", "uavenv_q_head_select", "uavenv_attn_core_forward", "uavenv_attn_core_backward", "uavenv_get_state",
     "uavenv_set_state", "uavenv_state_bytes", "uavenv_reset_host", "uavenv_step_host", "uavenv_time_steps",
 ]
 
@@ -166,6 +166,8 @@ def _load(path):
         "uavenv_gemm_f32": (C.c_int, [C.POINTER(UavGemm), C.POINTER(UavGemm), vp]),
         "uavenv_td_loss": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp, vp]),
         "uavenv_q_head_select": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, C.c_uint64, C.c_int32, vp, vp, vp]),
+        "uavenv_attn_core_forward": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]),
+        "uavenv_attn_core_backward": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]),
         "uavenv_clip_adam": (C.c_int, [vp, vp, vp, vp, C.c_int64, vp, vp, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
         "uavenv_epsilon_greedy": (C.c_int, [vp, i32, i32, vp, vp, u64, i32, vp, vp]),
         "uavenv_frame_stack": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),

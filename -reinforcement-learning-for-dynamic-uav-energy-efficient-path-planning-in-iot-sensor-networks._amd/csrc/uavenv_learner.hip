@@ -415,6 +415,125 @@ __global__ __launch_bounds__(256) void q_head_select_kernel(const float* __restr
     }
 }
 
+// ---- the attention extractor's core for training: one query per sample over T <= 64 tokens of E = 64 channels, H <= 8 heads ---------
+// scores[h][t] = qk[h] . kv[t]  (qk: the query with the key projection and the 1/sqrt(d) folded in, learner.py AttentionFeatures.forward),
+// a = softmax over the unmasked t, mix[h] = sum_t a[h][t] kv[t] -- and its backward.  As PyTorch ops these are six batched products of
+// 4 x 64 x 50 per sample, for which the GEMM library launches 128 x 256 macro tiles (20 us each), plus masked_fill / softmax and their
+// backward: ~15 launches, ~130 us of a 450 us update.  Here: one wavefront per sample, the sample's 50 x 64 token tile in LDS (row
+// stride 65: a column walk hits 32 different banks), lanes = tokens for the products over channels, lanes = channels for the
+// products over tokens, the head-sized operands as LDS broadcasts.
+constexpr int kAcE = 64, kAcTmax = 64, kAcHmax = 8, kAcRow = kAcE + 1, kAcWaves = 1;   // (one wavefront per workgroup: a batch of 256 lands on 256 CUs)
+struct AcShared { float kv[kAcTmax * kAcRow]; float hq[kAcHmax * kAcE]; float ht[kAcHmax * kAcTmax]; float hs[kAcHmax * kAcTmax]; };
+
+__device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ float wave_sum(float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
+
+// the sample's token tile -> LDS: lane = channel, one coalesced row per step, all rows requested before the first store
+__device__ __forceinline__ void ac_load_tile(AcShared& sh, const float* __restrict__ kv, int T, int lane) {
+    float r[kAcTmax];
+#pragma unroll
+    for (int t = 0; t < kAcTmax; t++) r[t] = kv[(size_t)(t < T ? t : T - 1) * kAcE + lane];
+#pragma unroll
+    for (int t = 0; t < kAcTmax; t++) sh.kv[t * kAcRow + lane] = r[t];
+}
+
+template <int H>
+__global__ __launch_bounds__(64 * kAcWaves) void attn_core_fwd_kernel(const float* __restrict__ qk, const float* __restrict__ kv, const uint8_t* __restrict__ mask,
+                                                                     int B, int T, float* __restrict__ mix, float* __restrict__ attn) {
+    __shared__ AcShared shs[kAcWaves];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = __builtin_amdgcn_readfirstlane((int)blockIdx.x * kAcWaves + wave);
+    if (b >= B) return;                                        // (wave-uniform; no workgroup barrier below)
+    AcShared& sh = shs[wave];
+    ac_load_tile(sh, kv + (size_t)b * T * kAcE, T, lane);
+#pragma unroll
+    for (int h = 0; h < H; h++) sh.hq[h * kAcE + lane] = qk[((size_t)b * H + h) * kAcE + lane];
+    const bool on = lane < T && mask[(size_t)b * T + (lane < T ? lane : 0)] == 0;
+    __builtin_amdgcn_s_waitcnt(0);                            // (one wavefront per tile: LDS traffic is in order, no barrier needed)
+    float s[H];
+#pragma unroll
+    for (int h = 0; h < H; h++) s[h] = 0.f;
+    const int tr = (lane < T ? lane : T - 1) * kAcRow;
+#pragma unroll 8
+    for (int e = 0; e < kAcE; e++) {                           // lane = token: scores over the channels
+        const float x = sh.kv[tr + e];
+#pragma unroll
+        for (int h = 0; h < H; h++) s[h] += sh.hq[h * kAcE + e] * x;
+    }
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+        const float v = on ? s[h] : -3.0e38f;
+        const float m = wave_max(v);
+        const float p = on ? __expf(v - m) : 0.f;
+        const float a = p / wave_sum(p);
+        sh.ht[h * kAcTmax + lane] = a;
+        if (lane < T) attn[((size_t)b * H + h) * T + lane] = a;
+    }
+    float o[H];
+#pragma unroll
+    for (int h = 0; h < H; h++) o[h] = 0.f;
+    for (int t = 0; t < T; t++) {                              // lane = channel: the weighted mean of the tokens
+        const float x = sh.kv[t * kAcRow + lane];
+#pragma unroll
+        for (int h = 0; h < H; h++) o[h] += sh.ht[h * kAcTmax + t] * x;
+    }
+#pragma unroll
+    for (int h = 0; h < H; h++) mix[((size_t)b * H + h) * kAcE + lane] = o[h];
+}
+
+template <int H>
+__global__ __launch_bounds__(64 * kAcWaves) void attn_core_bwd_kernel(const float* __restrict__ qk, const float* __restrict__ kv, const float* __restrict__ attn,
+                                                                     const float* __restrict__ dmix, int B, int T, float* __restrict__ dqk,
+                                                                     float* __restrict__ dkv) {
+    __shared__ AcShared shs[kAcWaves];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = __builtin_amdgcn_readfirstlane((int)blockIdx.x * kAcWaves + wave);
+    if (b >= B) return;
+    AcShared& sh = shs[wave];
+    ac_load_tile(sh, kv + (size_t)b * T * kAcE, T, lane);
+    float q[H], g[H], a[H];
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+        q[h] = qk[((size_t)b * H + h) * kAcE + lane];
+        g[h] = dmix[((size_t)b * H + h) * kAcE + lane];
+        a[h] = lane < T ? attn[((size_t)b * H + h) * T + lane] : 0.f;
+        sh.hq[h * kAcE + lane] = g[h];                         // dmix, for the products over the channels
+        sh.ht[h * kAcTmax + lane] = a[h];
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    float da[H];
+#pragma unroll
+    for (int h = 0; h < H; h++) da[h] = 0.f;
+    const int tr = (lane < T ? lane : T - 1) * kAcRow;
+#pragma unroll 8
+    for (int e = 0; e < kAcE; e++) {                           // lane = token: da[h][t] = dmix[h] . kv[t]
+        const float x = sh.kv[tr + e];
+#pragma unroll
+        for (int h = 0; h < H; h++) da[h] += sh.hq[h * kAcE + e] * x;
+    }
+#pragma unroll
+    for (int h = 0; h < H; h++) {                              // softmax backward: ds = a (da - sum_t a da)
+        const float dot = wave_sum(a[h] * da[h]);
+        sh.hs[h * kAcTmax + lane] = a[h] * (da[h] - dot);
+    }
+    float o[H];
+#pragma unroll
+    for (int h = 0; h < H; h++) o[h] = 0.f;
+    for (int t = 0; t < T; t++) {                              // lane = channel: dqk[h] = sum_t ds[h][t] kv[t];  dkv[t] = sum_h a dmix + ds qk
+        const float x = sh.kv[t * kAcRow + lane];
+        float d = 0.f;
+#pragma unroll
+        for (int h = 0; h < H; h++) {
+            const float ds = sh.hs[h * kAcTmax + t];
+            o[h] += ds * x;
+            d += sh.ht[h * kAcTmax + t] * g[h] + ds * q[h];
+        }
+        dkv[((size_t)b * T + t) * kAcE + lane] = d;
+    }
+#pragma unroll
+    for (int h = 0; h < H; h++) dqk[((size_t)b * H + h) * kAcE + lane] = o[h];
+}
+
 }  // namespace
 
 // replaces: the three matrix products of torch.nn.Linear's forward / backward at DQN batch sizes (dqn.py:1086 batch_size 256).
@@ -514,5 +633,42 @@ extern "C" int uavenv_q_head_select(const float* h_dev, const float* w_dev, cons
         q_head_select_kernel<kSelMaxActions><<<dim3(wgs), dim3(256), lds, (hipStream_t)stream>>>(h_dev, w_dev, b_dev, n_envs, k, n_actions, eps_dev,
                                                                                              counter_dev, ticket_dev, seed, shared_coin,
                                                                                              actions_out_dev, q_out_dev);
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_E_HIP;
+}
+
+
+// replaces: the batched products + masked softmax at the centre of nn.MultiheadAttention's forward / backward for ONE query per sample
+// (dqn.py:633-640 cross_attn(query, keys, keys, key_padding_mask)), after the key / value projections have been folded out
+// (learner.py AttentionFeatures.forward).  qk float [B][H][64] (scaled query times the key projection), kv float [B][T][64] (the
+// tokens), mask uint8 [B][T] (1 = ignore; never a whole row), H in {1, 2, 4, 8}, T <= 64: mix float [B][H][64], attn float [B][H][T].
+extern "C" int uavenv_attn_core_forward(const float* qk_dev, const float* kv_dev, const uint8_t* mask_dev, int32_t batch, int32_t heads,
+                                        int32_t tokens, float* mix_out_dev, float* attn_out_dev, void* stream) {
+    if (!qk_dev || !kv_dev || !mask_dev || !mix_out_dev || !attn_out_dev || batch < 1 || tokens < 1 || tokens > kAcTmax) return UAVENV_E_INVALID;
+    const dim3 grid((unsigned)((batch + kAcWaves - 1) / kAcWaves)), block(64 * kAcWaves);
+    hipStream_t s = (hipStream_t)stream;
+    switch (heads) {
+    case 1: attn_core_fwd_kernel<1><<<grid, block, 0, s>>>(qk_dev, kv_dev, mask_dev, batch, tokens, mix_out_dev, attn_out_dev); break;
+    case 2: attn_core_fwd_kernel<2><<<grid, block, 0, s>>>(qk_dev, kv_dev, mask_dev, batch, tokens, mix_out_dev, attn_out_dev); break;
+    case 4: attn_core_fwd_kernel<4><<<grid, block, 0, s>>>(qk_dev, kv_dev, mask_dev, batch, tokens, mix_out_dev, attn_out_dev); break;
+    case 8: attn_core_fwd_kernel<8><<<grid, block, 0, s>>>(qk_dev, kv_dev, mask_dev, batch, tokens, mix_out_dev, attn_out_dev); break;
+    default: return UAVENV_E_INVALID;
+    }
+    return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_E_HIP;
+}
+
+// its backward: dmix float [B][H][64] in; dqk float [B][H][64], dkv float [B][T][64] out (both written whole).
+extern "C" int uavenv_attn_core_backward(const float* qk_dev, const float* kv_dev, const float* attn_dev, const float* dmix_dev, int32_t batch,
+                                         int32_t heads, int32_t tokens, float* dqk_out_dev, float* dkv_out_dev, void* stream) {
+    if (!qk_dev || !kv_dev || !attn_dev || !dmix_dev || !dqk_out_dev || !dkv_out_dev || batch < 1 || tokens < 1 || tokens > kAcTmax)
+        return UAVENV_E_INVALID;
+    const dim3 grid((unsigned)((batch + kAcWaves - 1) / kAcWaves)), block(64 * kAcWaves);
+    hipStream_t s = (hipStream_t)stream;
+    switch (heads) {
+    case 1: attn_core_bwd_kernel<1><<<grid, block, 0, s>>>(qk_dev, kv_dev, attn_dev, dmix_dev, batch, tokens, dqk_out_dev, dkv_out_dev); break;
+    case 2: attn_core_bwd_kernel<2><<<grid, block, 0, s>>>(qk_dev, kv_dev, attn_dev, dmix_dev, batch, tokens, dqk_out_dev, dkv_out_dev); break;
+    case 4: attn_core_bwd_kernel<4><<<grid, block, 0, s>>>(qk_dev, kv_dev, attn_dev, dmix_dev, batch, tokens, dqk_out_dev, dkv_out_dev); break;
+    case 8: attn_core_bwd_kernel<8><<<grid, block, 0, s>>>(qk_dev, kv_dev, attn_dev, dmix_dev, batch, tokens, dqk_out_dev, dkv_out_dev); break;
+    default: return UAVENV_E_INVALID;
+    }
     return hipGetLastError() == hipSuccess ? UAVENV_OK : UAVENV_E_HIP;
 }

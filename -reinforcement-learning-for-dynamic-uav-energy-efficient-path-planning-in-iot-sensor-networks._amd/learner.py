@@ -64,6 +64,40 @@ REFERENCE_HYPERPARAMS = dict(
 )
 
 
+class _AttentionCore(torch.autograd.Function):
+    """scores = qk . kv^T, masked softmax over the tokens, mix = attn . kv for one query per sample -- forward and backward in one
+    launch each (csrc/uavenv_learner.hip: attn_core_*_kernel) instead of six batched 4 x 64 x 50 products + masked_fill + softmax
+    and their backward (~15 launches, the GEMM library's 128 x 256 macro tiles at 20 us apiece)."""
+
+    @staticmethod
+    def forward(ctx, qk, kv, mask):
+        import ctypes as C
+        B, H, E = qk.shape
+        T = kv.shape[1]
+        qk, kv = qk.contiguous(), kv.contiguous()
+        m8 = mask.contiguous().view(torch.uint8)
+        mix = torch.empty(B, H, E, dtype=torch.float32, device=qk.device)
+        attn = torch.empty(B, H, T, dtype=torch.float32, device=qk.device)
+        N.check(N.lib().uavenv_attn_core_forward(C.c_void_p(qk.data_ptr()), C.c_void_p(kv.data_ptr()), C.c_void_p(m8.data_ptr()), B, H, T,
+                                                 C.c_void_p(mix.data_ptr()), C.c_void_p(attn.data_ptr()),
+                                                 C.c_void_p(torch.cuda.current_stream(qk.device).cuda_stream)))
+        ctx.save_for_backward(qk, kv, attn)
+        return mix
+
+    @staticmethod
+    def backward(ctx, dmix):
+        import ctypes as C
+        qk, kv, attn = ctx.saved_tensors
+        B, H, E = qk.shape
+        T = kv.shape[1]
+        dmix = dmix.contiguous()
+        dqk, dkv = torch.empty_like(qk), torch.empty_like(kv)
+        N.check(N.lib().uavenv_attn_core_backward(C.c_void_p(qk.data_ptr()), C.c_void_p(kv.data_ptr()), C.c_void_p(attn.data_ptr()),
+                                                  C.c_void_p(dmix.data_ptr()), B, H, T, C.c_void_p(dqk.data_ptr()), C.c_void_p(dkv.data_ptr()),
+                                                  C.c_void_p(torch.cuda.current_stream(qk.device).cuda_stream)))
+        return dqk, dkv, None
+
+
 class AttentionFeatures(nn.Module):
     """Layer for layer the architecture of the reference's UAVAttentionExtractor (dqn.py:548-650): an MLP over the UAV
     header of all stacked frames, one-query cross-attention over the 50 sensor slots of the newest frame with ghost
@@ -79,6 +113,7 @@ class AttentionFeatures(nn.Module):
         self.norm = nn.LayerNorm(embed)
         self.fuse = nn.Sequential(nn.Linear(2 * embed, features), nn.ReLU())
         self.features_dim = features
+        self.fused_core = True          # the scores / softmax / mix core of `forward` in the library's kernels (GPU); False: PyTorch ops
 
     def _inputs(self, obs):
         B = obs.shape[0]
@@ -108,13 +143,20 @@ class AttentionFeatures(nn.Module):
         B, H, E = obs.shape[0], self.attn.num_heads, self.attn.embed_dim
         d = E // H
         q = self.uav(uav)
-        kv = F.relu(torch.baddbmm(self.sensor.bias, sens, self.sensor.weight.t().expand(B, 3, E)))            # [B, T, E]
+        # (the bias rides along as a fourth input that is always 1: as `baddbmm(bias, ...)` its gradient is a [B, T, E] -> [E] reduction
+        #  that comes back STALE from HIP-graph replays on this PyTorch / ROCm build -- every other gradient of the module replays
+        #  correctly, tools/graph_grad_check.py -- while the [B, 4, E] -> [4, E] sum of the expanded weight's gradient does not)
+        w1 = torch.cat([self.sensor.weight.t(), self.sensor.bias.unsqueeze(0)], 0)                              # [4, E]
+        kv = F.relu(torch.bmm(F.pad(sens, (0, 1), value=1.0), w1.expand(B, 4, E)))                              # [B, T, E]
         wq, wk, wv = self.attn.in_proj_weight.view(3, H, d, E)
         bq, _, bv = self.attn.in_proj_bias.view(3, H, d)
         qh = (F.linear(q, wq.reshape(E, E), bq.reshape(E)) * d ** -0.5).view(B, H, d)
         qk = torch.einsum("bhd,hde->bhe", qh, wk)                                                              # [B, H, E]
-        scores = torch.bmm(qk, kv.transpose(1, 2)).masked_fill(mask.unsqueeze(1), float("-inf"))              # [B, H, T]
-        mix = torch.bmm(torch.softmax(scores, -1), kv)                                                         # [B, H, E]
+        if obs.is_cuda and E == 64 and self.slots <= 64 and H in (1, 2, 4, 8) and self.fused_core:
+            mix = _AttentionCore.apply(qk, kv, mask)                                                           # [B, H, E], one launch each way
+        else:
+            scores = torch.bmm(qk, kv.transpose(1, 2)).masked_fill(mask.unsqueeze(1), float("-inf"))          # [B, H, T]
+            mix = torch.bmm(torch.softmax(scores, -1), kv)                                                     # [B, H, E]
         ctx = (torch.einsum("bhe,hde->bhd", mix, wv) + bv).reshape(B, E)
         ctx = F.linear(ctx, self.attn.out_proj.weight, self.attn.out_proj.bias)
         return self.fuse(torch.cat([q, self.norm(ctx)], -1))

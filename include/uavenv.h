@@ -395,6 +395,18 @@ int uavenv_q_head_select(const float* h_dev, const float* w_dev, const float* b_
                          const float* eps_dev, float* counter_dev, int32_t* ticket_dev, uint64_t seed, int32_t shared_coin,
                          int32_t* actions_out_dev, float* q_out_dev, void* stream);
 
+/* replaces: the batched products and the masked softmax at the centre of nn.MultiheadAttention for ONE query per sample
+ * (dqn.py:633-640: cross_attn(query, keys, keys, key_padding_mask)) in the TRAINING step, forward and backward, once the key and
+ * value projections are folded out of the token dimension (uavenv_amd/learner.py AttentionFeatures.forward):
+ *   scores[h][t] = qk[h] . kv[t],  a = softmax over the tokens with mask == 0,  mix[h] = sum_t a[h][t] kv[t].
+ * qk_dev float [batch][heads][64], kv_dev float [batch][tokens][64], mask_dev uint8 [batch][tokens] (1 = ignore; never a whole row),
+ * heads in {1, 2, 4, 8}, tokens <= 64.  Forward writes mix float [batch][heads][64] and attn float [batch][heads][tokens] (kept for
+ * the backward); backward takes dmix and writes dqk float [batch][heads][64], dkv float [batch][tokens][64] (whole). */
+int uavenv_attn_core_forward(const float* qk_dev, const float* kv_dev, const uint8_t* mask_dev, int32_t batch, int32_t heads,
+                             int32_t tokens, float* mix_out_dev, float* attn_out_dev, void* stream);
+int uavenv_attn_core_backward(const float* qk_dev, const float* kv_dev, const float* attn_dev, const float* dmix_dev, int32_t batch,
+                              int32_t heads, int32_t tokens, float* dqk_out_dev, float* dkv_out_dev, void* stream);
+
 /* ---- state access (checkpoint / parity / the attribute reads of SURVEY 1) -------------------- */
 /* Copies one whole field.  `bytes` must equal the field size; dst/src may be host or device.
  * A state handed to uavenv_set_state must be one the library could have produced: 0 <= data_buffer <= max_buffer_size in every

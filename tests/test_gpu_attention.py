@@ -112,3 +112,80 @@ def test_folded_training_forward_equals_the_module_form_values_and_gradients(n_s
         scale = max(float(b.abs().max()), 1e-6)
         assert float((a - b).abs().max()) <= 2e-4 * scale + 1e-6, (name, float((a - b).abs().max()), scale)
     env.close()
+
+
+@pytest.mark.parametrize("B,H,T", [(256, 4, 50), (5, 4, 50), (64, 8, 64), (33, 1, 7), (16, 2, 33)])
+def test_attention_core_kernels_equal_the_pytorch_ops_forward_and_backward(B, H, T):
+    """uavenv_attn_core_forward / _backward (scores, masked softmax, weighted mean of the tokens for one query per sample, one launch
+    each way) against bmm + masked_fill + softmax + bmm and autograd through them: mix, and the gradients w.r.t. the folded query
+    and the tokens under the same upstream gradient.  Floating-point kernels: fp32 sums in another order -> 1e-5 on O(1) values."""
+    import torch
+    from uavenv_amd.learner import _AttentionCore
+    g = torch.Generator(device="cuda").manual_seed(B * 100 + T)
+    qk = torch.randn(B, H, 64, device="cuda", generator=g, requires_grad=True)
+    kv = torch.randn(B, T, 64, device="cuda", generator=g, requires_grad=True)
+    mask = torch.rand(B, T, device="cuda", generator=g) < 0.4
+    mask[:, 0] = False                                        # never a whole row
+    mask[0, 1:] = True                                        # one sample with a single visible token
+    up = torch.randn(B, H, 64, device="cuda", generator=g)
+    scores = torch.bmm(qk, kv.transpose(1, 2)).masked_fill(mask.unsqueeze(1), float("-inf"))
+    want = torch.bmm(torch.softmax(scores, -1), kv)
+    (want * up).sum().backward()
+    gq, gk = qk.grad.clone(), kv.grad.clone()
+    qk.grad = None; kv.grad = None
+    got = _AttentionCore.apply(qk, kv, mask)
+    (got * up).sum().backward()
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-5), float((got - want).abs().max())
+    assert torch.allclose(qk.grad, gq, rtol=1e-4, atol=2e-5), float((qk.grad - gq).abs().max())
+    assert torch.allclose(kv.grad, gk, rtol=1e-4, atol=2e-5), float((kv.grad - gk).abs().max())
+    assert bool((kv.grad[mask] == 0).all())                   # ignored tokens receive no gradient
+
+
+@pytest.mark.parametrize("form", ["folded_fused_core", "folded_torch_core"])
+def test_extractor_gradients_out_of_graph_replays_equal_eager_autograd_on_new_inputs(form):
+    """The training step replays the extractor's forward + backward as a HIP graph.  Every parameter's gradient out of a replay --
+    on inputs that CHANGED since the capture -- must be what eager autograd computes for them.  (The gradient of a bias handed to
+    torch.baddbmm, a [B, T, E] -> [E] reduction, comes back stale from replays on this PyTorch / ROCm build while a first replay on
+    unchanged inputs looks right: AttentionFeatures.forward carries the bias as a fourth always-one input instead.  The reference's form,
+    forward_module -- nn.Linear / nn.MultiheadAttention over the [B x 50] tokens -- has the same stale gradients for every token-level
+    bias (sensor.bias, the value third of attn.in_proj_bias: 12 800-row reductions); the learner replays only `forward`.)"""
+    import torch
+    m = _module(10).train()
+    m.fused_core = form == "folded_fused_core"
+    fwd = m.forward
+    params = list(m.parameters())
+    names = [n for n, _ in m.named_parameters()]
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.rand(256, 1530, device="cuda", generator=gen)
+    up = torch.randn(256, 128, device="cuda", generator=gen)
+    flat = torch.zeros(sum(p.numel() for p in params), device="cuda")
+
+    def step():
+        for p in params:
+            p.grad = None
+        (fwd(x) * up).sum().backward()
+        torch.cat([p.grad.reshape(-1) for p in params], out=flat)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    for change in (lambda: x.mul_(0.5), lambda: x.add_(0.1), lambda: up.neg_()):
+        change()
+        for p in params:
+            p.grad = None
+        (fwd(x) * up).sum().backward()
+        want = torch.cat([p.grad.reshape(-1) for p in params])
+        g.replay()
+        torch.cuda.synchronize()
+        off = 0
+        for name, p in zip(names, params):
+            k = p.numel()
+            a, b = flat[off:off + k], want[off:off + k]
+            off += k
+            assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-3), (form, name, float((a - b).abs().max()), float(b.abs().max()))
