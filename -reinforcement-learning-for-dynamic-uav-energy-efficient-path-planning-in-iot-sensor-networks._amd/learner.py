@@ -603,6 +603,14 @@ class DQNLearner:
         if self._fused is not None:
             self._fused.refresh(self.q.features)
 
+    def _train_graph_safe(self):
+        """May the update be replayed as a HIP graph?  The library's own update (MLP policy): always.  Updates with PyTorch autograd in
+        them (the attention extractor; `fused_update=False`): only up to a batch of 256 per rank -- on this PyTorch 2.10 / ROCm 7
+        build, reductions that autograd spreads over several workgroups (a bias gradient over >= 512 rows, the 12 800 token rows of
+        nn.Linear over [batch x 50]) come back STALE from graph replays (tools/graph_grad_check.py, BATCH=512); at 256 every
+        gradient replays exactly (tests/test_gpu_attention.py).  Above that the update runs eagerly; acting is replayed regardless."""
+        return (self._mlp is not None and not self._hybrid) or self.local_batch <= 256
+
     def _capture_train_graph(self):
         """One gradient step -- sample, TD loss, backward, clip, Adam -- as a graph.  Captured after eager updates have run
         (optimizer state and library workspaces exist); the ring's sampling window and the learning rate are device scalars
@@ -684,7 +692,7 @@ class DQNLearner:
     def train(self, gradient_steps=None):
         self._set_lr(self.lr_schedule(self.progress_remaining()))
         steps = self.gradient_steps if gradient_steps is None else gradient_steps
-        if self._graphs_usable() and self._train_graph is None and self._warm_upd >= 3:
+        if self._graphs_usable() and self._train_graph is None and self._warm_upd >= 3 and self._train_graph_safe():
             self._capture_train_graph()
         if self._train_graph is not None:
             self.ring.drain()                              # the gathers of finished chunks (host side; no-op alone)

@@ -471,3 +471,24 @@ def test_output_layer_and_selection_in_one_launch_equal_the_two_step_form(shared
                                         C.c_void_p(eps.data_ptr()), C.c_void_p(L._act_counter.data_ptr()), C.c_void_p(L._act_ticket.data_ptr()), 1, 0,
                                         C.c_void_p(L._act_out.data_ptr()), None, None) == N.E_INVALID
     env.close()
+
+
+def test_updates_with_autograd_in_them_are_not_graph_replayed_above_batch_256():
+    """Reductions that autograd spreads over several workgroups replay stale from HIP graphs on this stack (tools/graph_grad_check.py
+    at BATCH=512): with the attention extractor or the PyTorch update, a batch above 256 keeps the UPDATE eager (acting is still
+    replayed); the library's own MLP update is replayed at any batch."""
+    torch, U, LR = _mods()
+    def run(**kw):
+        env = U.BatchedUAVEnv(128, num_sensors=50, max_steps=9, grid_size=(60, 60), seed=5)
+        L = LR.DQNLearner(env, learning_rate=1e-3, buffer_size=128 * 40, gamma=0.9, learning_starts=0, target_update_interval=128 * 7,
+                          train_freq=2, gradient_steps=1, net_arch=(32, 16), total_timesteps=10**6, seed=3, reward_scale=1e-3, **kw)
+        for _ in range(8):
+            L.collect(L.train_freq); L.train()
+        torch.cuda.synchronize()
+        out = (L._act_graphs is not None, L._train_graph is not None, L.n_updates)
+        env.close()
+        return out
+    assert run(extractor="attention", n_stack=3, batch_size=512) == (True, False, 8)
+    assert run(extractor="attention", n_stack=3, batch_size=256) == (True, True, 8)
+    assert run(extractor="mlp", n_stack=4, batch_size=512, fused_update=False) == (True, False, 8)
+    assert run(extractor="mlp", n_stack=4, batch_size=512) == (True, True, 8)

@@ -11,7 +11,8 @@ m = LR.AttentionFeatures(10).cuda()
 m.fused_core = os.environ.get("FUSED_CORE", "1") == "1"
 params = list(m.parameters()); names = [n for n, _ in m.named_parameters()]
 n = sum(p.numel() for p in params)
-x = torch.rand(256, 1530, device="cuda"); up = torch.randn(256, 128, device="cuda")
+BATCH = int(os.environ.get("BATCH", 256))
+x = torch.rand(BATCH, 1530, device="cuda"); up = torch.randn(BATCH, 128, device="cuda")
 flat = torch.zeros(n, device="cuda")
 def step():
     for p in params: p.grad = None
